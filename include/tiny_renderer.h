@@ -1,0 +1,157 @@
+/*
+ * tiny_renderer.h -- C ABI of the MI355X-native triangle-fill path.
+ *
+ * Drop-in boundary: the reference has no FFI; its caller (src/app.rs:137-146,170,208-213)
+ * talks to the Rust methods of `Scene` (src/scene.rs:44-269).  Each entry point below names the
+ * method it replaces.  A Rust host binds these with an `extern "C"` block;
+ * everything is plain pointers, sizes and int status codes -- no exceptions cross this line.
+ *
+ * Call protocol per frame, as in app.rs:170,208-213:
+ *     tr_scene_clear -> tr_scene_set_light_direction -> tr_scene_set_camera ->
+ *     tr_scene_render -> tr_scene_get_frame_buffer
+ * `render` does not clear; calling it twice without `clear` depth-tests against the previous
+ * result exactly like the reference.  A tr_scene is not thread-safe (the reference's Scene is
+ * not even Send, shader.rs:85-87).  All rendering runs on the GPU; there is no CPU fallback:
+ * tr_scene_create fails with TR_E_HIP when no gfx950 device is usable.
+ */
+#ifndef TINY_RENDERER_H
+#define TINY_RENDERER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TR_ABI_VERSION 1
+
+/* Status codes.  0 = ok, negative = failure (the reference panics at the cited site). */
+enum {
+    TR_OK = 0,
+    TR_E_INVALID = -1,          /* bad argument / NULL handle */
+    TR_E_UNKNOWN_PIPELINE = -2, /* shader.rs:108 */
+    TR_E_BAD_POLYGON = -3,      /* scene.rs:218, or an index outside positions/tex_coords/normals */
+    TR_E_SINGULAR = -4,         /* try_inverse().unwrap(): shader.rs:224,277,278,631; :921 */
+    TR_E_OOB_LOOKUP = -5,       /* device error word: texture / shadow-buffer index out of range
+                                   (util.rs:40,52,68,82; shader.rs:778,912,935) or w == 0
+                                   (shader.rs:158); the frame is produced but parity is undefined */
+    TR_E_HIP = -6,              /* HIP runtime failure or no usable device */
+    TR_E_IO = -7,               /* file missing / unreadable (app.rs:94,99: `?`) */
+    TR_E_FORMAT = -8,           /* unsupported OBJ / TGA content */
+    TR_E_BIN_OVERFLOW = -9,     /* triangle-bin capacity exceeded; raise tr_options.bin_capacity */
+    TR_E_NOMEM = -10
+};
+
+/* obj::raw::RawObj as the path reads it (util.rs:25-31, shader.rs:136-147,363-367,
+ * scene.rs:216-226).  Indices are zero based; a polygon contributes its first three
+ * (position, tex_coord, normal) triples. */
+typedef struct tr_mesh {
+    const float *pos;    /* n_pos * 3  (obj-rs keeps a 4th w component; the path ignores it) */
+    const float *tex;    /* n_tex * 3 */
+    const float *nrm;    /* n_nrm * 3 */
+    const uint32_t *idx; /* n_tri * 9 : p0,t0,n0, p1,t1,n1, p2,t2,n2 */
+    uint32_t n_pos, n_tex, n_nrm, n_tri;
+} tr_mesh;
+
+/* image::RgbImage: tightly packed rgb8, row 0 = top of the picture. */
+typedef struct tr_image_rgb8 {
+    const uint8_t *rgb;
+    uint32_t w, h;
+} tr_image_rgb8;
+
+#define TR_OPT_WINNER_TAP 0x1u /* keep a per-pixel winning-polygon index (parity tap) */
+
+typedef struct tr_options {
+    uint32_t struct_size;      /* = sizeof(tr_options) */
+    int32_t device;            /* HIP device ordinal; -1 = current device */
+    uint32_t flags;            /* TR_OPT_* */
+    /* Screen-band shard (multi-GPU): this scene renders only output-image rows
+     * [band_row0, band_row1) (row 0 = top, as returned by get_frame_buffer).
+     * 0,0 = the whole frame. */
+    uint32_t band_row0, band_row1;
+    void *stream;              /* hipStream_t to enqueue on; NULL = library-owned stream */
+    void *frame_buffer_device; /* device pointer to 3*W*H bytes to render into (e.g. the
+                                  all-gather buffer); NULL = library-owned */
+    uint64_t bin_capacity;     /* triangle-bin entries; 0 = default */
+} tr_options;
+
+typedef struct tr_scene tr_scene;
+
+/* Scene::new (scene.rs:47-88).  tex[] = texture, normal_map, normal_map_tangent, specular_map
+ * (the order of Scene::new's arguments).  Inputs are copied (the reference moves them).
+ * Pipeline names: shader.rs:100-109 (`true_normal`, README.md:18, is accepted as an alias of
+ * `normal_map`). */
+int tr_scene_create(uint32_t width, uint32_t height, const tr_mesh *mesh,
+                    const tr_image_rgb8 tex[4], const char *pipeline_name,
+                    const tr_options *opts, tr_scene **out);
+void tr_scene_destroy(tr_scene *s);
+
+int tr_scene_clear(tr_scene *s);                                  /* scene.rs:128-137 */
+int tr_scene_set_light_direction(tr_scene *s, const float v[3]); /* scene.rs:140-142 */
+int tr_scene_set_camera(tr_scene *s, const float look_from[3], const float look_at[3],
+                        const float up[3]);                       /* scene.rs:145-149 */
+int tr_scene_render(tr_scene *s);                                 /* scene.rs:151-268 (async) */
+
+/* scene.rs:92-125.  Caller-owned host buffers of 3*W*H bytes, row 0 = top.  Synchronizes.
+ * Returns the sticky device status (TR_E_OOB_LOOKUP, TR_E_BIN_OVERFLOW) of the frame. */
+int tr_scene_get_frame_buffer(tr_scene *s, uint8_t *rgb);
+int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb);
+int tr_scene_get_shadow_buffer(tr_scene *s, uint8_t *rgb);
+
+/* Parity taps, not in the reference: raw buffers in the reference's internal layout
+ * (index = x + y*W, row 0 = bottom), W*H elements. */
+int tr_scene_read_z_f32(tr_scene *s, float *out);
+int tr_scene_read_shadow_f32(tr_scene *s, float *out);
+int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out); /* needs TR_OPT_WINNER_TAP;
+                                                             0xFFFFFFFF = no fragment */
+
+/* Device-resident access for callers that keep the frame on the GPU. */
+int tr_scene_sync(tr_scene *s);                 /* wait for queued work; returns frame status */
+void *tr_scene_frame_buffer_device(tr_scene *s); /* 3*W*H bytes, row 0 = top */
+int tr_scene_set_stream(tr_scene *s, void *hip_stream);
+
+/* Per-kernel device timing with HIP events on the scene's stream (bench roofline leg). */
+typedef struct tr_kernel_time {
+    char name[32];
+    uint64_t launches;
+    double total_ms;
+} tr_kernel_time;
+int tr_scene_profile_enable(tr_scene *s, int on);
+/* Fills up to `cap` entries, returns the number of kernels or a negative status. */
+int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap);
+
+/* shader.rs:97-112 registry */
+int tr_pipeline_count(void);
+const char *tr_pipeline_name(int i);
+
+/* shader.rs:183-279 prepares, host-side (no GPU needed).  kind: 0 default_prepare,
+ * 1 shadow_pass_prepare_1, 2 shadow_pass_prepare_2.  Matrices column-major (nalgebra). */
+typedef struct tr_uniforms {
+    float camera_direction[3];
+    float t_light_direction[3];
+    float vpmv[16];
+    float i_vpmv[16];
+    float m[16];
+    float i_m[16];
+    float it_m[16];
+    float shadow_matrix[16];
+} tr_uniforms;
+int tr_prepare_uniforms(int kind, tr_uniforms *u, uint32_t width, uint32_t height,
+                        const float light[3], const float look_from[3],
+                        const float look_at[3], const float up[3]);
+
+/* Asset loading (app.rs:87-131): obj-rs `parse_obj` and image `open(..).into_rgb8()`
+ * counterparts.  Returned objects are owned by the library; free with the matching call. */
+int tr_load_obj(const char *path, tr_mesh **out);
+void tr_free_mesh(tr_mesh *m);
+int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out);
+void tr_free_image(tr_image_rgb8 *img);
+
+const char *tr_last_error(void);
+int tr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+"""ctypes loader for lib/libtiny_renderer.so (built in-tree from csrc/ by `make`)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = os.path.join(_HERE, "lib", "libtiny_renderer.so")
+
+TR_OK = 0
+TR_E_INVALID = -1
+TR_E_UNKNOWN_PIPELINE = -2
+TR_E_BAD_POLYGON = -3
+TR_E_SINGULAR = -4
+TR_E_OOB_LOOKUP = -5
+TR_E_HIP = -6
+TR_E_IO = -7
+TR_E_FORMAT = -8
+TR_E_BIN_OVERFLOW = -9
+TR_E_NOMEM = -10
+
+TR_OPT_WINNER_TAP = 0x1
+
+
+class TinyRendererError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("tiny_renderer error %d: %s" % (code, message))
+        self.code = code
+
+
+class Mesh(C.Structure):
+    _fields_ = [("pos", C.POINTER(C.c_float)), ("tex", C.POINTER(C.c_float)),
+                ("nrm", C.POINTER(C.c_float)), ("idx", C.POINTER(C.c_uint32)),
+                ("n_pos", C.c_uint32), ("n_tex", C.c_uint32), ("n_nrm", C.c_uint32),
+                ("n_tri", C.c_uint32)]
+
+
+class ImageRgb8(C.Structure):
+    _fields_ = [("rgb", C.POINTER(C.c_uint8)), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("band_row0", C.c_uint32), ("band_row1", C.c_uint32), ("stream", C.c_void_p),
+                ("frame_buffer_device", C.c_void_p), ("bin_capacity", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class Uniforms(C.Structure):
+    _fields_ = [("camera_direction", C.c_float * 3), ("t_light_direction", C.c_float * 3),
+                ("vpmv", C.c_float * 16), ("i_vpmv", C.c_float * 16), ("m", C.c_float * 16),
+                ("i_m", C.c_float * 16), ("it_m", C.c_float * 16),
+                ("shadow_matrix", C.c_float * 16)]
+
+
+# Every symbol include/tiny_renderer.h declares: name -> (restype, argtypes)
+_FP = C.POINTER(C.c_float)
+SYMBOLS = {
+    "tr_scene_create": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(Mesh), C.POINTER(ImageRgb8),
+                                  C.c_char_p, C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "tr_scene_destroy": (None, [C.c_void_p]),
+    "tr_scene_clear": (C.c_int, [C.c_void_p]),
+    "tr_scene_set_light_direction": (C.c_int, [C.c_void_p, _FP]),
+    "tr_scene_set_camera": (C.c_int, [C.c_void_p, _FP, _FP, _FP]),
+    "tr_scene_render": (C.c_int, [C.c_void_p]),
+    "tr_scene_get_frame_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_get_z_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_get_shadow_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_read_z_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_read_shadow_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_read_winner_u32": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_sync": (C.c_int, [C.c_void_p]),
+    "tr_scene_frame_buffer_device": (C.c_void_p, [C.c_void_p]),
+    "tr_scene_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "tr_scene_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int]),
+    "tr_pipeline_count": (C.c_int, []),
+    "tr_pipeline_name": (C.c_char_p, [C.c_int]),
+    "tr_prepare_uniforms": (C.c_int, [C.c_int, C.POINTER(Uniforms), C.c_uint32, C.c_uint32,
+                                      _FP, _FP, _FP, _FP]),
+    "tr_load_obj": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(Mesh))]),
+    "tr_free_mesh": (None, [C.POINTER(Mesh)]),
+    "tr_load_tga_rgb8": (C.c_int, [C.c_char_p, C.POINTER(ImageRgb8)]),
+    "tr_free_image": (None, [C.POINTER(ImageRgb8)]),
+    "tr_last_error": (C.c_char_p, []),
+    "tr_abi_version": (C.c_int, []),
+}
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False, quiet=True):
+    """Compile csrc/ for gfx950 with hipcc (csrc/Makefile) into lib/libtiny_renderer.so."""
+    cmd = ["make", "-C", _CSRC, "-j4"] + (["-B"] if force else [])
+    if quiet:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the C-ABI library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise TinyRendererError(TR_E_HIP, "%s is missing: run `make -C %s` (or "
+                                    "__graft_entry__.build()); there is no CPU fallback" % (_LIB, _CSRC))
+        L = C.CDLL(_LIB)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code < 0:
+        msg = load_library().tr_last_error()
+        raise TinyRendererError(code, msg.decode() if msg else "")
+    return code

@@ -1,0 +1,242 @@
+// tr_loaders.cpp -- asset loading behind the C ABI (tr_load_obj, tr_load_tga_rgb8).
+//
+// Counterparts of what src/app.rs:87-131 gets from third-party crates:
+//   obj-rs 0.7.0 `parse_obj`           -> positions / tex_coords / normals / polygons
+//   image 0.24.5 `open(..).into_rgb8()` -> tightly packed rgb8, row 0 = top
+// Only what the path consumes is produced: the first three v/vt/vn triples of a face
+// (scene.rs:224-226), xyz of a position (util.rs:25-31).  Faces without all of v, vt and vn are
+// reported as TR_E_BAD_POLYGON, where the reference panics (scene.rs:218).
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "tiny_renderer.h"
+#include "tr_error.h"
+
+namespace {
+
+struct MeshOwner {
+    tr_mesh pub;
+    std::vector<float> pos, tex, nrm;
+    std::vector<uint32_t> idx;
+};
+
+bool read_file(const char *path, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) {
+        fclose(f);
+        return false;
+    }
+    out.resize((size_t)n);
+    size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == (size_t)n;
+}
+
+// Parses up to `want` floats from s (strtof: correctly rounded, like Rust's str::parse::<f32>).
+int parse_floats(const char *s, float *dst, int want)
+{
+    int n = 0;
+    while (n < want) {
+        char *end = nullptr;
+        errno = 0;
+        float v = strtof(s, &end);
+        if (end == s) break;
+        dst[n++] = v;
+        s = end;
+    }
+    return n;
+}
+
+// One "v/vt/vn" group.  Returns false unless all three indices are present.
+bool parse_ptn(const char *&s, long count[3], uint32_t out[3])
+{
+    while (*s == ' ' || *s == '\t') s++;
+    if (*s == '\0' || *s == '\n' || *s == '\r') return false;
+    for (int k = 0; k < 3; k++) {
+        char *end = nullptr;
+        long v = strtol(s, &end, 10);
+        if (end == s) return false;
+        // OBJ indices are 1-based; negative ones are relative to the end of the list
+        long z = v > 0 ? v - 1 : count[k] + v;
+        if (v == 0 || z < 0 || z >= count[k]) return false;
+        out[k] = (uint32_t)z;
+        s = end;
+        if (k < 2) {
+            if (*s != '/') return false;
+            s++;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int tr_load_obj(const char *path, tr_mesh **out)
+{
+    if (!path || !out) return tr::fail(TR_E_INVALID, "tr_load_obj: null argument");
+    *out = nullptr;
+    std::vector<uint8_t> data;
+    if (!read_file(path, data)) return tr::fail(TR_E_IO, std::string("cannot read ") + path);
+    data.push_back('\n');
+    data.push_back('\0');
+
+    MeshOwner *m = new MeshOwner();
+    int status = TR_OK;
+    std::string why;
+    char *p = reinterpret_cast<char *>(data.data());
+    long line_no = 0;
+    while (*p) {
+        char *eol = strchr(p, '\n');
+        *eol = '\0';
+        line_no++;
+        const char *s = p;
+        while (*s == ' ' || *s == '\t') s++;
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            float v[4] = { 0, 0, 0, 1 };
+            if (parse_floats(s + 1, v, 4) < 3) {
+                status = TR_E_FORMAT;
+                why = "bad vertex position";
+            }
+            m->pos.insert(m->pos.end(), v, v + 3);
+        } else if (s[0] == 'v' && s[1] == 't' && (s[2] == ' ' || s[2] == '\t')) {
+            float v[3] = { 0, 0, 0 };
+            if (parse_floats(s + 2, v, 3) < 1) {
+                status = TR_E_FORMAT;
+                why = "bad texture coordinate";
+            }
+            m->tex.insert(m->tex.end(), v, v + 3);
+        } else if (s[0] == 'v' && s[1] == 'n' && (s[2] == ' ' || s[2] == '\t')) {
+            float v[3] = { 0, 0, 0 };
+            if (parse_floats(s + 2, v, 3) < 3) {
+                status = TR_E_FORMAT;
+                why = "bad vertex normal";
+            }
+            m->nrm.insert(m->nrm.end(), v, v + 3);
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            long count[3] = { (long)(m->pos.size() / 3), (long)(m->tex.size() / 3), (long)(m->nrm.size() / 3) };
+            const char *q = s + 1;
+            uint32_t tri[9];
+            bool ok = true;
+            for (int k = 0; k < 3 && ok; k++) ok = parse_ptn(q, count, &tri[3 * k]);
+            if (!ok) {
+                status = TR_E_BAD_POLYGON;
+                why = "face is not three or more v/vt/vn groups with valid indices";
+            } else {
+                m->idx.insert(m->idx.end(), tri, tri + 9);
+            }
+        }
+        if (status != TR_OK) {
+            why += " (line " + std::to_string(line_no) + " of " + path + ")";
+            break;
+        }
+        p = eol + 1;
+    }
+    if (status != TR_OK) {
+        delete m;
+        return tr::fail(status, why);
+    }
+    m->pub.pos = m->pos.data();
+    m->pub.tex = m->tex.data();
+    m->pub.nrm = m->nrm.data();
+    m->pub.idx = m->idx.data();
+    m->pub.n_pos = (uint32_t)(m->pos.size() / 3);
+    m->pub.n_tex = (uint32_t)(m->tex.size() / 3);
+    m->pub.n_nrm = (uint32_t)(m->nrm.size() / 3);
+    m->pub.n_tri = (uint32_t)(m->idx.size() / 9);
+    *out = &m->pub;  // pub is the first member: the owner is recovered by a cast in tr_free_mesh
+    return TR_OK;
+}
+
+extern "C" void tr_free_mesh(tr_mesh *mesh)
+{
+    if (mesh) delete reinterpret_cast<MeshOwner *>(mesh);
+}
+
+// TGA: image types 2 (true colour), 3 (grey), 10 / 11 (their run-length forms); 8, 24 or 32
+// bits per pixel; either vertical origin.  Colour-mapped and 15/16-bit files are rejected.
+extern "C" int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out)
+{
+    if (!path || !out) return tr::fail(TR_E_INVALID, "tr_load_tga_rgb8: null argument");
+    out->rgb = nullptr;
+    out->w = out->h = 0;
+    std::vector<uint8_t> d;
+    if (!read_file(path, d)) return tr::fail(TR_E_IO, std::string("cannot read ") + path);
+    if (d.size() < 18) return tr::fail(TR_E_FORMAT, std::string("truncated TGA header: ") + path);
+    const uint32_t id_len = d[0], cmap_type = d[1], type = d[2];
+    const uint32_t cmap_len = d[5] | (d[6] << 8), cmap_bits = d[7];
+    const uint32_t w = d[12] | (d[13] << 8), h = d[14] | (d[15] << 8), bpp = d[16], desc = d[17];
+    const bool rle = (type == 10 || type == 11), grey = (type == 3 || type == 11);
+    if (!(type == 2 || type == 3 || type == 10 || type == 11))
+        return tr::fail(TR_E_FORMAT, std::string("unsupported TGA image type in ") + path);
+    if ((grey && bpp != 8) || (!grey && bpp != 24 && bpp != 32))
+        return tr::fail(TR_E_FORMAT, std::string("unsupported TGA pixel depth in ") + path);
+    const size_t bytes_pp = bpp / 8, npx = (size_t)w * h;
+    size_t pos = 18 + id_len + (cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0);
+
+    std::vector<uint8_t> raw(npx * bytes_pp);
+    if (!rle) {
+        if (pos + raw.size() > d.size()) return tr::fail(TR_E_FORMAT, std::string("truncated TGA data: ") + path);
+        if (!raw.empty()) memcpy(raw.data(), &d[pos], raw.size());
+    } else {
+        size_t px = 0;
+        while (px < npx) {
+            if (pos >= d.size()) return tr::fail(TR_E_FORMAT, std::string("truncated TGA run: ") + path);
+            const uint8_t hd = d[pos++];
+            size_t run = (size_t)(hd & 0x7F) + 1;
+            if (px + run > npx) run = npx - px;
+            if (hd & 0x80) {
+                if (pos + bytes_pp > d.size()) return tr::fail(TR_E_FORMAT, std::string("truncated TGA run: ") + path);
+                for (size_t i = 0; i < run; i++) memcpy(&raw[(px + i) * bytes_pp], &d[pos], bytes_pp);
+                pos += bytes_pp;
+            } else {
+                if (pos + run * bytes_pp > d.size()) return tr::fail(TR_E_FORMAT, std::string("truncated TGA run: ") + path);
+                memcpy(&raw[px * bytes_pp], &d[pos], run * bytes_pp);
+                pos += run * bytes_pp;
+            }
+            px += run;
+        }
+    }
+
+    uint8_t *rgb = (uint8_t *)malloc(npx ? npx * 3 : 1);
+    if (!rgb) return tr::fail(TR_E_NOMEM, "tr_load_tga_rgb8: out of memory");
+    const bool top_origin = (desc & 0x20) != 0, right_origin = (desc & 0x10) != 0;
+    for (uint32_t y = 0; y < h; y++) {
+        const uint32_t sy = top_origin ? y : h - 1 - y;
+        for (uint32_t x = 0; x < w; x++) {
+            const uint32_t sx = right_origin ? w - 1 - x : x;
+            const uint8_t *s = &raw[((size_t)sy * w + sx) * bytes_pp];
+            uint8_t *t = &rgb[((size_t)y * w + x) * 3];
+            if (grey) {
+                t[0] = t[1] = t[2] = s[0];
+            } else {
+                t[0] = s[2];
+                t[1] = s[1];
+                t[2] = s[0];
+            }
+        }
+    }
+    out->rgb = rgb;
+    out->w = w;
+    out->h = h;
+    return TR_OK;
+}
+
+extern "C" void tr_free_image(tr_image_rgb8 *img)
+{
+    if (img && img->rgb) {
+        free(const_cast<uint8_t *>(img->rgb));
+        img->rgb = nullptr;
+        img->w = img->h = 0;
+    }
+}

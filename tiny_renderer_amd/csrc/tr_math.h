@@ -1,0 +1,147 @@
+// tr_math.h -- f32 vector/matrix primitives in the reference's operation order.
+//
+// The reference does all arithmetic through nalgebra 0.31.4 (SURVEY.md Appendix A lists the
+// call sites).  Every function here performs the same IEEE binary32 operations in the same
+// order; the translation unit must be built with -ffp-contract=off and without fast-math so
+// that no a*b+c is fused and '/' and sqrt stay correctly rounded.
+//
+// Usable from HIP device code and from plain host C++ (the tests build a host-side emulation
+// of the kernels from these headers).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TR_HD __host__ __device__ __forceinline__
+#else
+#define TR_HD inline
+#endif
+
+namespace tr {
+
+struct vec3 {
+    float x, y, z;
+};
+
+TR_HD vec3 make3(float x, float y, float z)
+{
+    vec3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+TR_HD vec3 sub3(vec3 a, vec3 b) { return make3(a.x - b.x, a.y - b.y, a.z - b.z); }
+TR_HD vec3 add3(vec3 a, vec3 b) { return make3(a.x + b.x, a.y + b.y, a.z + b.z); }
+TR_HD vec3 scale3(vec3 a, float s) { return make3(a.x * s, a.y * s, a.z * s); }
+// Vector3::dot, unrolled for dimension 3: (a0*b0 + a1*b1) + a2*b2
+TR_HD float dot3(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+TR_HD vec3 cross3(vec3 a, vec3 b)
+{
+    return make3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// normalize(): n = sqrt(dot(v,v)), then a true division per component.
+TR_HD vec3 normalize3(vec3 a)
+{
+    float n = sqrtf(dot3(a, a));
+    return make3(a.x / n, a.y / n, a.z / n);
+}
+
+// Column-major 4x4 (element (r,c) = m[4*c + r]) times (x,y,z,w): nalgebra's gemv accumulates
+// column by column: y = col0*x; y = col1*y' + y; ...
+struct vec4 {
+    float x, y, z, w;
+};
+TR_HD vec4 mul_m4_v4(const float *m, float x, float y, float z, float w)
+{
+    vec4 r;
+    r.x = m[0] * x;
+    r.y = m[1] * x;
+    r.z = m[2] * x;
+    r.w = m[3] * x;
+    r.x = m[4] * y + r.x;
+    r.y = m[5] * y + r.y;
+    r.z = m[6] * y + r.z;
+    r.w = m[7] * y + r.w;
+    r.x = m[8] * z + r.x;
+    r.y = m[9] * z + r.y;
+    r.z = m[10] * z + r.z;
+    r.w = m[11] * z + r.w;
+    r.x = m[12] * w + r.x;
+    r.y = m[13] * w + r.y;
+    r.z = m[14] * w + r.z;
+    r.w = m[15] * w + r.w;
+    return r;
+}
+
+// Column-major 3x3 given as three columns.
+TR_HD vec3 mul_m3_v3(vec3 c0, vec3 c1, vec3 c2, vec3 v)
+{
+    vec3 r = make3(c0.x * v.x, c0.y * v.x, c0.z * v.x);
+    r = make3(c1.x * v.y + r.x, c1.y * v.y + r.y, c1.z * v.y + r.z);
+    r = make3(c2.x * v.z + r.x, c2.y * v.z + r.y, c2.z * v.z + r.z);
+    return r;
+}
+
+// Rust `as` casts: truncate toward zero, saturate, NaN -> 0.
+TR_HD int32_t f32_to_i32(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)v;
+}
+TR_HD uint32_t f32_to_u32(float v)
+{
+    if (!(v == v)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    if (v <= 0.0f) return 0u;
+    return (uint32_t)v;
+}
+TR_HD uint32_t f32_to_u8(float v)
+{
+    if (!(v == v)) return 0u;
+    if (v >= 255.0f) return 255u;
+    if (v <= 0.0f) return 0u;
+    return (uint32_t)v;
+}
+
+// util.rs:7-13 with color_2 = (0,0,0), one channel: (t*c + (1-t)*0.0) as u8.  The second term
+// is kept: it turns t = +-inf into NaN -> 0 like the reference.
+TR_HD uint32_t blend_black(uint32_t c, float t)
+{
+    return f32_to_u8(t * (float)c + (1.0f - t) * 0.0f);
+}
+
+TR_HD uint32_t f32_bits(float f)
+{
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.f = f;
+    return c.u;
+}
+TR_HD float bits_f32(uint32_t u)
+{
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.u = u;
+    return c.f;
+}
+
+// Monotone map f32 -> u32 (total order of finite floats and infinities); -0.0 is folded onto
+// +0.0 first because the reference's `z <= zbuf` treats them as equal.
+TR_HD uint32_t depth_order_key(float z)
+{
+    uint32_t b = f32_bits(z);
+    if (b == 0x80000000u) b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+#define TR_F32_MIN_BITS 0xFF7FFFFFu /* f32::MIN */
+
+}  // namespace tr

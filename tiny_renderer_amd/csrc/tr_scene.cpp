@@ -1,0 +1,753 @@
+// tr_scene.cpp -- host side of the C ABI: scene state, pass sequencing, buffer ownership.
+//
+// Mirrors the role of the reference's `Scene` (src/scene.rs:25-269) and `ShaderPipeline`
+// registry (src/scene/shader.rs:97-112) for a device-resident frame: the model, textures,
+// z / shadow / frame buffers live in HBM for the life of the scene; a frame is a handful of
+// kernel launches on one HIP stream and nothing is copied unless a getter is called.
+//
+// There is no CPU rendering path in this library.  If HIP or a gfx950 device is not usable,
+// tr_scene_create fails with TR_E_HIP.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "tiny_renderer.h"
+#include "tr_error.h"
+#include "tr_kernels.h"
+#include "tr_math.h"
+#include "tr_prepare.h"
+#include "tr_types.h"
+
+namespace tr {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+}  // namespace tr
+
+using namespace tr;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return tr::fail(TR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+namespace {
+
+struct PassDesc {
+    int prepare_kind;  // 0 default_prepare, 1 shadow_pass_prepare_1, 2 shadow_pass_prepare_2
+    int vs, fs;
+};
+
+struct PipelineDesc {
+    const char *name;
+    int n_passes;
+    PassDesc pass[2];
+};
+
+// shader.rs:100-109 and the pass lists of shader.rs:282-963
+const PipelineDesc kPipelines[P_COUNT] = {
+    { "default", 1, { { 0, VS_DEFAULT, FS_DEFAULT }, {} } },
+    { "phong", 1, { { 0, VS_PHONG, FS_PHONG }, {} } },
+    { "normal_map", 1, { { 0, VS_PLAIN, FS_NORMAL_MAP }, {} } },
+    { "specular", 1, { { 0, VS_PLAIN, FS_SPECULAR }, {} } },
+    { "darboux", 1, { { 0, VS_DARBOUX, FS_DARBOUX }, {} } },
+    { "shadow", 2, { { 1, VS_DEPTH, FS_DEPTH }, { 2, VS_PHONG, FS_SHADOW2 } } },
+    { "occlusion", 2, { { 1, VS_DEPTH, FS_DEPTH }, { 2, VS_PLAIN, FS_OCCLUSION2 } } },
+};
+
+const char *kKernelNames[] = { "k_setup", "k_scan", "k_fill", "k_tile", "k_tile_depth", "k_clear" };
+enum KernelId { K_SETUP = 0, K_SCAN, K_FILL, K_TILE, K_TILE_DEPTH, K_CLEAR, K_COUNT };
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+}  // namespace
+
+struct tr_scene {
+    uint32_t width = 0, height = 0;
+    int pipeline = 0;
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // Scene::new defaults, scene.rs:66-69
+    float light[3] = { 0.0f, 0.0f, -1.0f };
+    float from[3] = { 0.0f, 0.0f, 1.0f };
+    float at[3] = { 0.0f, 0.0f, 0.0f };
+    float up[3] = { 0.0f, 1.0f, 0.0f };
+
+    DevMesh mesh = {};
+    DevTextures tex = {};
+    DevFrame frame = {};       // the rows this scene owns (colour passes)
+    DevFrame frame_full = {};  // the whole frame: depth passes fill the entire shadow buffer, whose
+                               // lookups are in light space and can land anywhere (shader.rs:774-778)
+    uint32_t n_tiles = 0, n_tiles_full = 0;
+
+    // device allocations
+    float *d_pos = nullptr, *d_tex = nullptr, *d_nrm = nullptr;
+    uint32_t *d_idx = nullptr;
+    uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
+    RasterRec *d_rast = nullptr;
+    float *d_vary = nullptr;
+    uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr;
+    uint32_t *d_bins = nullptr;
+    uint64_t bin_capacity = 0;
+    float *d_z = nullptr, *d_shadow = nullptr;
+    uint8_t *d_fb = nullptr;
+    bool own_fb = false;
+    uint8_t *d_view = nullptr;  // scratch for get_z_buffer / get_shadow_buffer
+    uint32_t *d_winner = nullptr;
+    uint32_t *d_err = nullptr;
+
+    // Lazy clear (scene.rs:128-137): `clear` only records that the targets are logically
+    // f32::MIN / 0; the next render writes every pixel of them anyway, and a getter that comes
+    // first materialises the values.
+    bool z_fb_cleared = false;    // z buffer, frame buffer (and winner tap) are logically cleared
+    bool shadow_cleared = false;  // shadow buffer is logically cleared
+
+    tr_uniforms uniforms = {};
+    int host_status = TR_OK;  // sticky failure of the last render's host-side prepare
+
+    bool profiling = false;
+    std::vector<EventPair> events;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[K_COUNT] = {};
+    uint64_t prof_n[K_COUNT] = {};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, size_t count)
+{
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
+    return TR_OK;
+}
+
+template <typename T>
+void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+hipEvent_t take_event(tr_scene *s)
+{
+    if (!s->event_pool.empty()) {
+        hipEvent_t e = s->event_pool.back();
+        s->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Timed {
+    tr_scene *s;
+    EventPair ep;
+    bool on;
+    Timed(tr_scene *sc, int kernel) : s(sc), on(false)
+    {
+        ep.kernel = kernel;
+        ep.a = ep.b = nullptr;
+        if (s->profiling && s->events.size() < (1u << 20)) {
+            ep.a = take_event(s);
+            ep.b = take_event(s);
+            if (ep.a && ep.b && hipEventRecord(ep.a, s->stream) == hipSuccess) on = true;
+        }
+    }
+    ~Timed()
+    {
+        if (on && hipEventRecord(ep.b, s->stream) == hipSuccess) s->events.push_back(ep);
+    }
+};
+
+int drain_events(tr_scene *s)
+{
+    for (const EventPair &ep : s->events) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            s->prof_ms[ep.kernel] += ms;
+            s->prof_n[ep.kernel] += 1;
+        }
+        s->event_pool.push_back(ep.a);
+        s->event_pool.push_back(ep.b);
+    }
+    s->events.clear();
+    return TR_OK;
+}
+
+int launch_status(int rc, const char *what)
+{
+    if (rc == 0) return TR_OK;
+    return tr::fail(TR_E_HIP, std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
+}
+
+// Materialise a pending clear of the z / frame buffers (and winner tap).
+int flush_clear_color(tr_scene *s)
+{
+    if (!s->z_fb_cleared) return TR_OK;
+    // only the rows this scene owns: in a band-sharded frame the rest belongs to other ranks
+    const size_t W = s->width;
+    const size_t n = W * (size_t)(s->frame.band_y1 - s->frame.band_y0);
+    const size_t z_first = W * (size_t)s->frame.band_y0;
+    const size_t fb_first = W * (size_t)(s->height - (uint32_t)s->frame.band_y1) * 3;
+    Timed t(s, K_CLEAR);
+    int rc = launch_fill_u32(reinterpret_cast<uint32_t *>(s->d_z) + z_first, TR_F32_MIN_BITS, n, s->stream);
+    if (rc) return launch_status(rc, "clear z");
+    HIP_TRY(hipMemsetAsync(s->d_fb + fb_first, 0, n * 3, s->stream));
+    if (s->d_winner) HIP_TRY(hipMemsetAsync(s->d_winner + z_first, 0xFF, n * 4, s->stream));
+    s->z_fb_cleared = false;
+    return TR_OK;
+}
+
+int flush_clear_shadow(tr_scene *s)
+{
+    if (!s->shadow_cleared) return TR_OK;
+    const size_t n = (size_t)s->width * s->height;
+    Timed t(s, K_CLEAR);
+    int rc = launch_fill_u32(reinterpret_cast<uint32_t *>(s->d_shadow), TR_F32_MIN_BITS, n, s->stream);
+    if (rc) return launch_status(rc, "clear shadow");
+    s->shadow_cleared = false;
+    return TR_OK;
+}
+
+// Waits for the stream and folds the device error word into a status.
+int sync_and_status(tr_scene *s)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
+    if (s->host_status != TR_OK) return s->host_status;
+    if (err & DE_BIN_OVERFLOW)
+        return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins overflowed; raise tr_options.bin_capacity");
+    if (err & (DE_W_ZERO | DE_TEX_OOB | DE_SHADOW_OOB | DE_SINGULAR)) {
+        char buf[160];
+        snprintf(buf, sizeof buf,
+                 "device lookups left their range (bits 0x%x: 1 w==0, 2 texture, 4 shadow buffer, 8 singular basis)",
+                 err);
+        return tr::fail(TR_E_OOB_LOOKUP, buf);
+    }
+    return TR_OK;
+}
+
+void fill_dev_uniforms(const tr_scene *s, DevUniforms &d)
+{
+    const tr_uniforms &u = s->uniforms;
+    memcpy(d.vpmv, u.vpmv, sizeof d.vpmv);
+    memcpy(d.m, u.m, sizeof d.m);
+    memcpy(d.it_m, u.it_m, sizeof d.it_m);
+    memcpy(d.shadow_matrix, u.shadow_matrix, sizeof d.shadow_matrix);
+    memcpy(d.i_vpmv, u.i_vpmv, sizeof d.i_vpmv);
+    memcpy(d.camera_direction, u.camera_direction, sizeof d.camera_direction);
+    memcpy(d.t_light, u.t_light_direction, sizeof d.t_light);
+    memset(d.sm_ivpmv, 0, sizeof d.sm_ivpmv);
+    memset(d.occl_steps, 0, sizeof d.occl_steps);
+}
+
+int run_pass(tr_scene *s, const PassDesc &p)
+{
+    int st = prepare_uniforms(p.prepare_kind, &s->uniforms, s->width, s->height, s->light, s->from, s->at, s->up);
+    if (st != TR_OK) return tr::fail(st, "prepare: singular matrix (try_inverse().unwrap() would panic)");
+
+    DevUniforms du;
+    fill_dev_uniforms(s, du);
+    if (p.fs == FS_SHADOW2 || p.fs == FS_OCCLUSION2) shadow_times_inverse(&s->uniforms, du.sm_ivpmv);
+    if (p.fs == FS_OCCLUSION2) {
+        st = occlusion_steps(&s->uniforms, du.occl_steps);
+        if (st != TR_OK) return tr::fail(st, "occlusion: rotation_between(..).unwrap() would panic");
+    }
+
+    const bool depth_pass = (p.fs == FS_DEPTH);
+    // Which targets does this pass write, and are they logically cleared?
+    uint32_t fresh;
+    if (depth_pass) {
+        fresh = s->shadow_cleared ? 1u : 0u;
+        s->shadow_cleared = false;
+    } else {
+        fresh = s->z_fb_cleared ? 1u : 0u;
+        s->z_fb_cleared = false;
+        // a colour pass that reads the shadow buffer needs real values in it
+        if (p.fs == FS_SHADOW2 || p.fs == FS_OCCLUSION2) {
+            st = flush_clear_shadow(s);
+            if (st != TR_OK) return st;
+        }
+    }
+
+    const DevFrame &frame = depth_pass ? s->frame_full : s->frame;
+    const uint32_t n_tiles = depth_pass ? s->n_tiles_full : s->n_tiles;
+
+    SetupArgs sa;
+    sa.mesh = s->mesh;
+    sa.frame = frame;
+    sa.u = du;
+    sa.rast = s->d_rast;
+    sa.vary = s->d_vary;
+    sa.tile_count = s->d_tile_count;
+    sa.err = s->d_err;
+    {
+        Timed t(s, K_SETUP);
+        int rc = launch_setup(p.vs, sa, s->stream);
+        if (rc) return launch_status(rc, "k_setup");
+    }
+
+    ScanArgs sc;
+    sc.tile_count = s->d_tile_count;
+    sc.tile_offset = s->d_tile_offset;
+    sc.tile_cursor = s->d_tile_cursor;
+    sc.n_tiles = n_tiles;
+    sc.capacity = s->bin_capacity;
+    sc.err = s->d_err;
+    {
+        Timed t(s, K_SCAN);
+        int rc = launch_scan(sc, s->stream);
+        if (rc) return launch_status(rc, "k_scan");
+    }
+
+    FillArgs fa;
+    fa.rast = s->d_rast;
+    fa.frame = frame;
+    fa.n_tri = s->mesh.n_tri;
+    fa.tile_offset = s->d_tile_offset;
+    fa.tile_cursor = s->d_tile_cursor;
+    fa.bins = s->d_bins;
+    fa.capacity = s->bin_capacity;
+    {
+        Timed t(s, K_FILL);
+        int rc = launch_fill(fa, s->stream);
+        if (rc) return launch_status(rc, "k_fill");
+    }
+
+    TileArgs ta;
+    ta.rast = s->d_rast;
+    ta.vary = s->d_vary;
+    ta.bins = s->d_bins;
+    ta.tile_offset = s->d_tile_offset;
+    ta.tile_count = s->d_tile_count;
+    ta.frame = frame;
+    ta.u = du;
+    ta.tex = s->tex;
+    ta.zbuf = s->d_z;
+    ta.shadow = s->d_shadow;
+    ta.fb = s->d_fb;
+    ta.winner = s->d_winner;
+    ta.err = s->d_err;
+    ta.bin_capacity = s->bin_capacity;
+    ta.fresh = fresh;
+    ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
+    ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
+    {
+        Timed t(s, depth_pass ? K_TILE_DEPTH : K_TILE);
+        int rc = launch_tile(p.fs, ta, s->stream);
+        if (rc) return launch_status(rc, "k_tile");
+    }
+    return TR_OK;
+}
+
+int find_pipeline(const char *name)
+{
+    if (!name) return -1;
+    if (!strcmp(name, "true_normal")) name = "normal_map";  // README.md:18 spelling
+    for (int i = 0; i < P_COUNT; i++)
+        if (!strcmp(name, kPipelines[i].name)) return i;
+    return -1;
+}
+
+void destroy(tr_scene *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (const EventPair &ep : s->events) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
+    dev_free(s->d_pos);
+    dev_free(s->d_tex);
+    dev_free(s->d_nrm);
+    dev_free(s->d_idx);
+    for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
+    dev_free(s->d_rast);
+    dev_free(s->d_vary);
+    dev_free(s->d_tile_count);
+    dev_free(s->d_tile_offset);
+    dev_free(s->d_tile_cursor);
+    dev_free(s->d_bins);
+    dev_free(s->d_z);
+    dev_free(s->d_shadow);
+    if (s->own_fb) dev_free(s->d_fb);
+    dev_free(s->d_view);
+    dev_free(s->d_winner);
+    dev_free(s->d_err);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_rgb8 tex[4],
+           const char *pipeline_name, const tr_options *opts, tr_scene *s)
+{
+    const int pipe = find_pipeline(pipeline_name);
+    if (pipe < 0) return tr::fail(TR_E_UNKNOWN_PIPELINE, "Provided pipeline name is not supported!");
+    if (width == 0 || height == 0 || width > 32768u || height > 32768u)
+        return tr::fail(TR_E_INVALID, "frame size must be within 1..32768");
+    if (!mesh || !tex) return tr::fail(TR_E_INVALID, "null mesh or textures");
+    if (mesh->n_tri >= 0xFFFFFFF0u) return tr::fail(TR_E_INVALID, "too many polygons");
+    for (uint32_t t = 0; t < mesh->n_tri; t++) {
+        const uint32_t *ix = mesh->idx + 9u * (size_t)t;
+        for (int k = 0; k < 3; k++)
+            if (ix[3 * k] >= mesh->n_pos || ix[3 * k + 1] >= mesh->n_tex || ix[3 * k + 2] >= mesh->n_nrm)
+                return tr::fail(TR_E_BAD_POLYGON, "polygon index outside positions / tex_coords / normals");
+    }
+    for (int k = 0; k < 4; k++)
+        if (!tex[k].rgb || tex[k].w == 0 || tex[k].h == 0 || tex[k].w > 65535u || tex[k].h > 65535u)
+            return tr::fail(TR_E_INVALID, "texture must be non-empty and at most 65535 on a side");
+
+    tr_options o;
+    memset(&o, 0, sizeof o);
+    o.device = -1;
+    if (opts) memcpy(&o, opts, opts->struct_size < sizeof o ? opts->struct_size : sizeof o);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return tr::fail(TR_E_HIP, "no HIP device available (this library has no CPU rendering path)");
+    int dev = o.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return tr::fail(TR_E_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(dev));
+    s->device = dev;
+    s->width = width;
+    s->height = height;
+    s->pipeline = pipe;
+    s->flags = o.flags;
+
+    if (o.stream) {
+        s->stream = (hipStream_t)o.stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->own_stream = true;
+    }
+
+    // band (output rows, row 0 = top) -> internal rows (row 0 = bottom)
+    uint32_t r0 = o.band_row0, r1 = o.band_row1;
+    if (r0 == 0 && r1 == 0) r1 = height;
+    if (r0 >= r1 || r1 > height) return tr::fail(TR_E_INVALID, "band rows must satisfy row0 < row1 <= height");
+    s->frame.width = width;
+    s->frame.height = height;
+    s->frame.band_y0 = (int32_t)(height - r1);
+    s->frame.band_y1 = (int32_t)(height - r0);
+    s->frame.ntx = (width + TILE_W - 1) / TILE_W;
+    s->frame.ty_base = s->frame.band_y0 / TILE_H;
+    s->frame.nty = (uint32_t)((s->frame.band_y1 - 1) / TILE_H - s->frame.ty_base + 1);
+    s->n_tiles = s->frame.ntx * s->frame.nty;
+    s->frame_full = s->frame;
+    s->frame_full.band_y0 = 0;
+    s->frame_full.band_y1 = (int32_t)height;
+    s->frame_full.ty_base = 0;
+    s->frame_full.nty = (height + TILE_H - 1) / TILE_H;
+    s->n_tiles_full = s->frame_full.ntx * s->frame_full.nty;
+
+    const size_t npx = (size_t)width * height;
+    int st;
+    // model
+    if ((st = dev_alloc(&s->d_pos, (size_t)mesh->n_pos * 3))) return st;
+    if ((st = dev_alloc(&s->d_tex, (size_t)mesh->n_tex * 3))) return st;
+    if ((st = dev_alloc(&s->d_nrm, (size_t)mesh->n_nrm * 3))) return st;
+    if ((st = dev_alloc(&s->d_idx, (size_t)mesh->n_tri * 9))) return st;
+    HIP_TRY(hipMemcpy(s->d_pos, mesh->pos, (size_t)mesh->n_pos * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_tex, mesh->tex, (size_t)mesh->n_tex * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_nrm, mesh->nrm, (size_t)mesh->n_nrm * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_idx, mesh->idx, (size_t)mesh->n_tri * 36, hipMemcpyHostToDevice));
+    s->mesh.pos = s->d_pos;
+    s->mesh.tex = s->d_tex;
+    s->mesh.nrm = s->d_nrm;
+    s->mesh.idx = s->d_idx;
+    s->mesh.n_tri = mesh->n_tri;
+
+    // textures: rgb8 -> rgba8 so a texel is one aligned dword fetch
+    for (int k = 0; k < 4; k++) {
+        const size_t n = (size_t)tex[k].w * tex[k].h;
+        std::vector<uint32_t> rgba(n);
+        for (size_t i = 0; i < n; i++)
+            rgba[i] = (uint32_t)tex[k].rgb[3 * i] | ((uint32_t)tex[k].rgb[3 * i + 1] << 8) |
+                      ((uint32_t)tex[k].rgb[3 * i + 2] << 16);
+        if ((st = dev_alloc(&s->d_texel[k], n))) return st;
+        HIP_TRY(hipMemcpy(s->d_texel[k], rgba.data(), n * 4, hipMemcpyHostToDevice));
+        s->tex.texel[k] = s->d_texel[k];
+        s->tex.w[k] = tex[k].w;
+        s->tex.h[k] = tex[k].h;
+    }
+
+    // per-polygon records and bins
+    if ((st = dev_alloc(&s->d_rast, (size_t)mesh->n_tri))) return st;
+    if ((st = dev_alloc(&s->d_vary, (size_t)mesh->n_tri * VARY_STRIDE))) return st;
+    if ((st = dev_alloc(&s->d_tile_count, (size_t)s->n_tiles_full))) return st;
+    if ((st = dev_alloc(&s->d_tile_offset, (size_t)s->n_tiles_full + 1))) return st;
+    if ((st = dev_alloc(&s->d_tile_cursor, (size_t)s->n_tiles_full))) return st;
+    uint64_t cap = o.bin_capacity;
+    if (cap == 0) {
+        cap = (uint64_t)mesh->n_tri * s->n_tiles_full;  // every polygon in every tile
+        const uint64_t cap_max = 64ull << 20;      // 64 Mi entries = 256 MiB of the 288 GB
+        if (cap > cap_max) cap = cap_max;
+    }
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    if (cap < 1024) cap = 1024;
+    s->bin_capacity = cap;
+    if ((st = dev_alloc(&s->d_bins, (size_t)cap))) return st;
+    HIP_TRY(hipMemset(s->d_tile_count, 0, (size_t)s->n_tiles_full * 4));
+    HIP_TRY(hipMemset(s->d_tile_cursor, 0, (size_t)s->n_tiles_full * 4));
+
+    // render targets; Buffer::new / Scene::new zero-fill them (shader.rs:46-47, scene.rs:71)
+    if ((st = dev_alloc(&s->d_z, npx))) return st;
+    if ((st = dev_alloc(&s->d_shadow, npx))) return st;
+    HIP_TRY(hipMemset(s->d_z, 0, npx * 4));
+    HIP_TRY(hipMemset(s->d_shadow, 0, npx * 4));
+    if (o.frame_buffer_device) {
+        s->d_fb = (uint8_t *)o.frame_buffer_device;
+    } else {
+        if ((st = dev_alloc(&s->d_fb, npx * 3))) return st;
+        s->own_fb = true;
+        HIP_TRY(hipMemset(s->d_fb, 0, npx * 3));
+    }
+    if (o.flags & TR_OPT_WINNER_TAP) {
+        if ((st = dev_alloc(&s->d_winner, npx))) return st;
+        HIP_TRY(hipMemset(s->d_winner, 0xFF, npx * 4));
+    }
+    if ((st = dev_alloc(&s->d_err, 1))) return st;
+    HIP_TRY(hipMemset(s->d_err, 0, 4));
+    HIP_TRY(hipDeviceSynchronize());
+    return TR_OK;
+}
+
+int read_back(tr_scene *s, void *dst, const void *src, size_t bytes)
+{
+    int st = sync_and_status(s);
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return st;
+}
+
+int depth_view(tr_scene *s, const float *src, uint8_t *rgb)
+{
+    const size_t npx = (size_t)s->width * s->height;
+    if (!s->d_view) {
+        int st = dev_alloc(&s->d_view, npx * 3);
+        if (st) return st;
+    }
+    int rc = launch_depth_view(src, s->d_view, s->width, s->height, s->stream);
+    if (rc) return launch_status(rc, "k_depth_view");
+    return read_back(s, rgb, s->d_view, npx * 3);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int tr_abi_version(void) { return TR_ABI_VERSION; }
+
+const char *tr_last_error(void) { return tr::g_last_error.c_str(); }
+
+int tr_pipeline_count(void) { return P_COUNT; }
+
+const char *tr_pipeline_name(int i) { return (i >= 0 && i < P_COUNT) ? kPipelines[i].name : nullptr; }
+
+int tr_prepare_uniforms(int kind, tr_uniforms *u, uint32_t width, uint32_t height, const float light[3],
+                        const float look_from[3], const float look_at[3], const float up[3])
+{
+    if (!u || !light || !look_from || !look_at || !up) return tr::fail(TR_E_INVALID, "null argument");
+    return prepare_uniforms(kind, u, width, height, light, look_from, look_at, up);
+}
+
+int tr_scene_create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_rgb8 tex[4],
+                    const char *pipeline_name, const tr_options *opts, tr_scene **out)
+{
+    if (!out) return tr::fail(TR_E_INVALID, "null out pointer");
+    *out = nullptr;
+    tr_scene *s = new tr_scene();
+    int st = create(width, height, mesh, tex, pipeline_name, opts, s);
+    if (st != TR_OK) {
+        std::string keep = tr::g_last_error;
+        destroy(s);
+        tr::g_last_error = keep;
+        return st;
+    }
+    *out = s;
+    return TR_OK;
+}
+
+void tr_scene_destroy(tr_scene *s) { destroy(s); }
+
+int tr_scene_clear(tr_scene *s)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    s->z_fb_cleared = true;
+    s->shadow_cleared = true;
+    return TR_OK;
+}
+
+int tr_scene_set_light_direction(tr_scene *s, const float v[3])
+{
+    if (!s || !v) return tr::fail(TR_E_INVALID, "null argument");
+    memcpy(s->light, v, sizeof s->light);
+    return TR_OK;
+}
+
+int tr_scene_set_camera(tr_scene *s, const float look_from[3], const float look_at[3], const float up[3])
+{
+    if (!s || !look_from || !look_at || !up) return tr::fail(TR_E_INVALID, "null argument");
+    memcpy(s->from, look_from, sizeof s->from);
+    memcpy(s->at, look_at, sizeof s->at);
+    memcpy(s->up, up, sizeof s->up);
+    return TR_OK;
+}
+
+int tr_scene_render(tr_scene *s)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    s->host_status = TR_OK;
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    for (int i = 0; i < pd.n_passes; i++) {
+        int st = run_pass(s, pd.pass[i]);
+        if (st != TR_OK) {
+            s->host_status = st;
+            return st;
+        }
+    }
+    return TR_OK;
+}
+
+int tr_scene_sync(tr_scene *s)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    return sync_and_status(s);
+}
+
+void *tr_scene_frame_buffer_device(tr_scene *s) { return s ? s->d_fb : nullptr; }
+
+int tr_scene_set_stream(tr_scene *s, void *hip_stream)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->own_stream) (void)hipStreamDestroy(s->stream);
+    s->own_stream = false;
+    if (hip_stream) {
+        s->stream = (hipStream_t)hip_stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->own_stream = true;
+    }
+    return TR_OK;
+}
+
+int tr_scene_get_frame_buffer(tr_scene *s, uint8_t *rgb)
+{
+    if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    return read_back(s, rgb, s->d_fb, (size_t)s->width * s->height * 3);
+}
+
+int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb)
+{
+    if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    return depth_view(s, s->d_z, rgb);
+}
+
+int tr_scene_get_shadow_buffer(tr_scene *s, uint8_t *rgb)
+{
+    if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_shadow(s);
+    if (st != TR_OK) return st;
+    return depth_view(s, s->d_shadow, rgb);
+}
+
+int tr_scene_read_z_f32(tr_scene *s, float *out)
+{
+    if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    return read_back(s, out, s->d_z, (size_t)s->width * s->height * 4);
+}
+
+int tr_scene_read_shadow_f32(tr_scene *s, float *out)
+{
+    if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_shadow(s);
+    if (st != TR_OK) return st;
+    return read_back(s, out, s->d_shadow, (size_t)s->width * s->height * 4);
+}
+
+int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out)
+{
+    if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
+    if (!s->d_winner) return tr::fail(TR_E_INVALID, "scene was created without TR_OPT_WINNER_TAP");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    return read_back(s, out, s->d_winner, (size_t)s->width * s->height * 4);
+}
+
+int tr_scene_profile_enable(tr_scene *s, int on)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    drain_events(s);
+    s->profiling = on != 0;
+    if (on) {
+        memset(s->prof_ms, 0, sizeof s->prof_ms);
+        memset(s->prof_n, 0, sizeof s->prof_n);
+    }
+    return TR_OK;
+}
+
+int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap)
+{
+    if (!s || !out || cap <= 0) return tr::fail(TR_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    drain_events(s);
+    int n = 0;
+    for (int k = 0; k < K_COUNT && n < cap; k++) {
+        if (s->prof_n[k] == 0) continue;
+        memset(&out[n], 0, sizeof out[n]);
+        strncpy(out[n].name, kKernelNames[k], sizeof out[n].name - 1);
+        out[n].launches = s->prof_n[k];
+        out[n].total_ms = s->prof_ms[k];
+        n++;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+// tr_types.h -- plain-data structures shared by the host code and the HIP kernels.
+#pragma once
+
+#include <stdint.h>
+
+namespace tr {
+
+// shader.rs:100-109
+enum Pipeline : int {
+    P_DEFAULT = 0,
+    P_PHONG,
+    P_NORMAL_MAP,
+    P_SPECULAR,
+    P_DARBOUX,
+    P_SHADOW,
+    P_OCCLUSION,
+    P_COUNT
+};
+
+// Vertex-stage variants (the `vertex` closures of shader.rs).
+enum VsKind : int {
+    VS_DEFAULT = 0,  // shader.rs:285-316   cull + face-normal intensity
+    VS_PHONG,        // shader.rs:349-384, 711-747   cull + per-vertex intensities
+    VS_PLAIN,        // shader.rs:416-437, 475-496, 849-870   cull + transform + uv
+    VS_DARBOUX,      // shader.rs:549-595
+    VS_DEPTH,        // shader.rs:671-692, 809-830   no cull, shadow_matrix
+    VS_COUNT
+};
+
+// Fragment-stage variants (the `fragment` closures of shader.rs).
+enum FsKind : int {
+    FS_DEFAULT = 0,  // shader.rs:318-333
+    FS_PHONG,        // shader.rs:386-401
+    FS_NORMAL_MAP,   // shader.rs:439-459
+    FS_SPECULAR,     // shader.rs:498-534
+    FS_DARBOUX,      // shader.rs:597-655
+    FS_SHADOW2,      // shader.rs:749-788
+    FS_OCCLUSION2,   // shader.rs:872-947
+    FS_DEPTH,        // shader.rs:694-709, 832-847 (shadow-buffer fill, draws nothing)
+    FS_COUNT
+};
+
+// Screen tile owned by one 256-thread workgroup: 128 x 32 pixels, four 32 x 32 quadrants (one
+// per wavefront), each quadrant sixteen 8 x 8 lane blocks.  128 px of rgb8 = 384 B = three
+// 128-byte lines, 128 px of f32 depth = 512 B = four lines: every row a tile writes is made of
+// whole cache lines.
+constexpr int TILE_W = 128;
+constexpr int TILE_H = 32;
+constexpr int QUAD = 32;
+
+// Post-vertex record the coverage loop reads (64 B, fetched with scalar loads).
+// Mirrors Buffer.vertex_t_raster / vertex_z_values (shader.rs:34-35) plus the clamped
+// bounding box of scene.rs:233-239.  bx0 > bx1 marks a triangle that draws nothing (culled,
+// off screen, or degenerate: |cross.z| < 1, scene.rs:188-191).
+struct RasterRec {
+    int32_t x0, y0, x1, y1, x2, y2;
+    float z0, z1, z2;
+    int32_t bx0, bx1, by0, by1;
+    uint32_t pad[3];
+};
+static_assert(sizeof(RasterRec) == 64, "RasterRec must be 64 bytes");
+
+// Varyings gathered by the shading step, 24 floats (96 B) per triangle:
+//   [0..5]   vertex_uvs            u0,v0,u1,v1,u2,v2        (shader.rs:33)
+//   [6..8]   vertex_intensities                              (shader.rs:30)      default/phong/shadow
+//   darboux instead keeps, from vertex_t_positions / vertex_t_normals (shader.rs:31-32):
+//   [6..8]   normalize(tpos * (-1,1,0))    row 0 of the local basis (shader.rs:612-617)
+//   [9..11]  normalize(tpos * (-1,0,1))    row 1                    (shader.rs:618-623)
+//   [12..20] vertex_t_normals, column major
+constexpr int VARY_STRIDE = 24;
+
+// Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
+struct DevUniforms {
+    float vpmv[16];
+    float m[16];
+    float it_m[16];
+    float shadow_matrix[16];
+    float sm_ivpmv[16];  // shadow_matrix * i_vpmv (shader.rs:763-764, 899-900)
+    float i_vpmv[16];
+    float camera_direction[3];
+    float t_light[3];
+    float occl_steps[48];  // rot * (sin a_k, 0, cos a_k) * 0.02, k = 0..15 (shader.rs:916-929)
+};
+
+struct DevTextures {
+    const uint32_t *texel[4];  // rgba8 (a = 0), row 0 = top; texture, normal_map,
+                               // normal_map_tangent, specular_map
+    uint32_t w[4], h[4];
+};
+
+struct DevMesh {
+    const float *pos;
+    const float *tex;
+    const float *nrm;
+    const uint32_t *idx;
+    uint32_t n_tri;
+};
+
+// Geometry of the rendered region.
+struct DevFrame {
+    uint32_t width, height;
+    int32_t band_y0, band_y1;  // internal rows [y0, y1) (row 0 = bottom) this scene owns
+    uint32_t ntx, nty;         // tile grid covering the band
+    int32_t ty_base;           // first tile row (internal y / TILE_H)
+};
+
+// Device error word bits (reported as TR_E_OOB_LOOKUP / TR_E_BIN_OVERFLOW).
+enum DevErr : uint32_t {
+    DE_W_ZERO = 1u << 0,
+    DE_TEX_OOB = 1u << 1,
+    DE_SHADOW_OOB = 1u << 2,
+    DE_SINGULAR = 1u << 3,
+    DE_BIN_OVERFLOW = 1u << 4
+};
+
+struct SetupArgs {
+    DevMesh mesh;
+    DevFrame frame;
+    DevUniforms u;
+    RasterRec *rast;
+    float *vary;
+    uint32_t *tile_count;
+    uint32_t *err;
+};
+
+struct ScanArgs {
+    uint32_t *tile_count;
+    uint32_t *tile_offset;  // n_tiles + 1
+    uint32_t *tile_cursor;
+    uint32_t n_tiles;
+    uint64_t capacity;
+    uint32_t *err;
+};
+
+struct FillArgs {
+    const RasterRec *rast;
+    DevFrame frame;
+    uint32_t n_tri;
+    const uint32_t *tile_offset;
+    uint32_t *tile_cursor;
+    uint32_t *bins;
+    uint64_t capacity;
+};
+
+struct TileArgs {
+    const RasterRec *rast;
+    const float *vary;
+    const uint32_t *bins;
+    const uint32_t *tile_offset;
+    uint32_t *tile_count;  // reset to 0 by the tile kernel for the next pass
+    DevFrame frame;
+    DevUniforms u;
+    DevTextures tex;
+    float *zbuf;        // W*H, internal layout (row 0 = bottom)
+    float *shadow;      // W*H, internal layout
+    uint8_t *fb;        // 3*W*H, row 0 = top (already flipped: scene.rs:92-97 folded in)
+    uint32_t *winner;   // W*H or nullptr
+    uint32_t *err;
+    uint64_t bin_capacity;
+    uint32_t fresh;     // 1: target buffers are logically cleared (scene.rs:128-137 folded in)
+    uint32_t aligned16; // 1: width % 16 == 0, cleared rows can be written in 16-byte pieces
+    uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
+};
+
+}  // namespace tr

@@ -1,0 +1,149 @@
+"""Python mirror of the reference's `Scene` (src/scene.rs:25-269) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, load_library
+
+# shader.rs:100-109
+PIPELINES = ("default", "phong", "normal_map", "specular", "darboux", "shadow", "occlusion")
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _mesh_struct(mesh, keep):
+    pos = np.ascontiguousarray(mesh["pos"], np.float32).reshape(-1, 3)
+    tex = np.ascontiguousarray(mesh["tex"], np.float32).reshape(-1, 3)
+    nrm = np.ascontiguousarray(mesh["nrm"], np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(mesh["idx"], np.uint32).reshape(-1, 9)
+    keep += [pos, tex, nrm, idx]
+    fp = C.POINTER(C.c_float)
+    return _lib.Mesh(pos.ctypes.data_as(fp), tex.ctypes.data_as(fp), nrm.ctypes.data_as(fp),
+                     idx.ctypes.data_as(C.POINTER(C.c_uint32)), pos.shape[0], tex.shape[0],
+                     nrm.shape[0], idx.shape[0])
+
+
+class Scene:
+    """Scene::new(width, height, obj, texture, normal_map, normal_map_tangent, specular_map,
+    shader_pipeline_name) -- scene.rs:47-56.
+
+    mesh: dict of float32 pos[n,3], tex[n,3], nrm[n,3] and uint32 idx[n_tri,9]
+          (p0,t0,n0,p1,t1,n1,p2,t2,n2 -- obj::raw::RawObj as the path reads it).
+    textures: uint8 [h,w,3] arrays in Scene::new's order.
+    Extra keyword options are the tr_options of include/tiny_renderer.h.
+    """
+
+    def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
+                 winner_tap=False, band_rows=None, stream=None, frame_buffer_device=None,
+                 bin_capacity=0):
+        L = load_library()
+        self.width, self.height = int(width), int(height)
+        keep = []
+        m = _mesh_struct(mesh, keep)
+        imgs = (_lib.ImageRgb8 * 4)()
+        if len(textures) != 4:
+            raise ValueError("four textures are required (texture, normal_map, normal_map_tangent, specular_map)")
+        for k, t in enumerate(textures):
+            t = np.ascontiguousarray(t, np.uint8)
+            keep.append(t)
+            imgs[k] = _lib.ImageRgb8(t.ctypes.data_as(C.POINTER(C.c_uint8)), t.shape[1], t.shape[0])
+        o = _lib.Options()
+        o.struct_size = C.sizeof(_lib.Options)
+        o.device = device
+        o.flags = _lib.TR_OPT_WINNER_TAP if winner_tap else 0
+        if band_rows is not None:
+            o.band_row0, o.band_row1 = int(band_rows[0]), int(band_rows[1])
+        o.stream = stream
+        o.frame_buffer_device = frame_buffer_device
+        o.bin_capacity = int(bin_capacity)
+        h = C.c_void_p()
+        self._h = None
+        check(L.tr_scene_create(self.width, self.height, C.byref(m), imgs,
+                                shader_pipeline_name.encode(), C.byref(o), C.byref(h)))
+        self._h = h
+        self.pipeline = shader_pipeline_name
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().tr_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- the reference's methods -------------------------------------------------------------
+    def clear(self):
+        check(load_library().tr_scene_clear(self._h))
+
+    def set_light_direction(self, light_direction):
+        check(load_library().tr_scene_set_light_direction(self._h, _f3(light_direction)))
+
+    def set_camera(self, look_from, look_at, up):
+        check(load_library().tr_scene_set_camera(self._h, _f3(look_from), _f3(look_at), _f3(up)))
+
+    def render(self):
+        check(load_library().tr_scene_render(self._h))
+
+    def _image(self, fn, strict):
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        code = getattr(load_library(), fn)(self._h, out.ctypes.data)
+        if strict:
+            check(code)
+        self.last_status = code
+        return out
+
+    def get_frame_buffer(self, strict=True):
+        return self._image("tr_scene_get_frame_buffer", strict)
+
+    def get_z_buffer(self, strict=True):
+        return self._image("tr_scene_get_z_buffer", strict)
+
+    def get_shadow_buffer(self, strict=True):
+        return self._image("tr_scene_get_shadow_buffer", strict)
+
+    # --- parity taps / device-resident access -------------------------------------------------
+    def _raw(self, fn, dtype):
+        out = np.empty((self.height, self.width), dtype)
+        check(getattr(load_library(), fn)(self._h, out.ctypes.data))
+        return out
+
+    def read_z_f32(self):
+        return self._raw("tr_scene_read_z_f32", np.float32)
+
+    def read_shadow_f32(self):
+        return self._raw("tr_scene_read_shadow_f32", np.float32)
+
+    def read_winner_u32(self):
+        return self._raw("tr_scene_read_winner_u32", np.uint32)
+
+    def sync(self):
+        return check(load_library().tr_scene_sync(self._h))
+
+    def frame_buffer_device(self):
+        return load_library().tr_scene_frame_buffer_device(self._h)
+
+    def set_stream(self, stream):
+        check(load_library().tr_scene_set_stream(self._h, stream))
+
+    def profile_enable(self, on=True):
+        check(load_library().tr_scene_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        buf = (_lib.KernelTime * 16)()
+        n = check(load_library().tr_scene_profile_read(self._h, buf, 16))
+        return {buf[i].name.decode(): {"launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms)}
+                for i in range(n)}
+
+
+def prepare_uniforms(kind, width, height, light, look_from, look_at, up, uniforms=None):
+    """shader.rs:183-279 on the host (no GPU needed).  Returns (status, Uniforms)."""
+    u = uniforms if uniforms is not None else _lib.Uniforms()
+    st = load_library().tr_prepare_uniforms(kind, C.byref(u), width, height, _f3(light),
+                                            _f3(look_from), _f3(look_at), _f3(up))
+    return st, u
