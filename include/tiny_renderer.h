@@ -73,7 +73,8 @@ typedef struct tr_options {
     void *stream;              /* hipStream_t to enqueue on; NULL = library-owned stream */
     void *frame_buffer_device; /* device pointer to 3*W*H bytes to render into (e.g. the
                                   all-gather buffer); NULL = library-owned */
-    uint64_t bin_capacity;     /* triangle-bin entries; 0 = default */
+    uint64_t bin_capacity;     /* polygon ids per tile bin; 0 = default (1024); bins grow on
+                                  overflow and the frame is rendered again */
 } tr_options;
 
 typedef struct tr_scene tr_scene;

@@ -192,3 +192,18 @@ def test_full_size_properties_4096(synthetic):
     assert np.array_equal(zs[0].view(np.uint32), zs[1].view(np.uint32))
     assert np.array_equal(zs[1].view(np.uint32), zs[2].view(np.uint32))
     assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[1], masks[2])
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow"])
+def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
+    """More polygons per tile than the bins hold: the library grows the bins and renders the
+    frame again, transparently for a frame that started from clear()."""
+    mesh, texs = synthetic  # 5 022 polygons on a 256x256 frame: hundreds per 128x32 tile
+    gpu, cpu = render_pair(256, 256, mesh, texs, pipe, 0.3, 0.2, bin_capacity=64)
+    assert_parity(gpu, cpu, pipe)
+    # and the grown bins serve the next frame directly
+    for s in (gpu, cpu):
+        s.clear()
+        s.set_camera(*H.camera(1.3))
+        s.render()
+    assert_parity(gpu, cpu, pipe)

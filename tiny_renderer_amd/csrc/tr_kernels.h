@@ -10,8 +10,6 @@
 namespace tr {
 
 int launch_setup(int vs_kind, const SetupArgs &a, hipStream_t st);
-int launch_scan(const ScanArgs &a, hipStream_t st);
-int launch_fill(const FillArgs &a, hipStream_t st);
 int launch_tile(int fs_kind, const TileArgs &a, hipStream_t st);
 int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_depth_view(const float *src, uint8_t *dst, uint32_t W, uint32_t H, hipStream_t st);

@@ -3,11 +3,12 @@
 // The reference (src/scene.rs:151-268) is one serial loop nest: pass x polygon x bbox-x x
 // bbox-y, depth-testing and shading each covered pixel in polygon order.  Here a render pass is
 //
-//   k_setup   one thread per polygon: vertex closure, clamped bounding box, per-tile counts
-//   k_scan    one workgroup: exclusive scan of the per-tile counts
-//   k_fill    one thread per polygon: scatter polygon ids into per-tile bins
-//   k_tile    one 256-thread workgroup per 128x32 screen tile: coverage + depth resolve in LDS,
-//             then shading of the winners and a single streaming write of depth and colour
+//   k_setup   one thread per polygon: vertex closure, clamped bounding box, then the wavefront
+//             spreads its (polygon, tile) pairs over all 64 lanes and appends polygon ids to
+//             fixed-capacity per-tile bins (one atomic per pair)
+//   k_tile    one 256-thread workgroup per 128x32 screen tile: the bin's records are staged in
+//             LDS, coverage + depth resolve run against LDS keys, then the winners are shaded and
+//             depth and colour are streamed out once
 //
 // Equivalence with the serial loop: `z <= zbuf -> reject` in polygon order means the surviving
 // fragment of a pixel is the one with the largest z, ties going to the lowest polygon index, and
@@ -30,6 +31,8 @@ constexpr int NBX = QUAD / 8;    // 8x8 lane blocks per quadrant row
 constexpr int NBY = TILE_H / 8;  // block rows per quadrant
 constexpr int QPIX = QUAD * TILE_H;
 constexpr uint32_t NO_WINNER = 0xFFFFFFFFu;
+constexpr int SHADE_G = 2;  // row pairs shaded together (memory-level parallelism vs registers)
+constexpr int CHUNK = 64;  // polygons staged in LDS per round (256 threads x 16 B)
 
 __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int32_t ty)
 {
@@ -42,87 +45,86 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 template <int VS>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 {
+    // per-wave table for the pair distribution: exclusive pair offsets and tile ranges
+    __shared__ int32_t s_excl[4][64], s_tx0[4][64], s_ty0[4][64], s_ntx[4][64];
+    __shared__ uint32_t s_tri[4][64];
+
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.mesh.n_tri) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool active = t < a.mesh.n_tri;
 
-    RasterRec r;
-    float vary[VARY_STRIDE];
-#pragma unroll
-    for (int i = 0; i < VARY_STRIDE; i++) vary[i] = 0.0f;
+    int32_t tx0 = 0, ty0 = 0, ntx = 0, cnt = 0;
     uint32_t err = 0;
-    const bool keep = vertex_stage<VS>(a.mesh, a.u, t, r, vary, err);
-    if (keep)
-        finish_raster_rec(r, a.frame);
-    else
-        mark_rejected(r);
-
-    uint4 *dst = reinterpret_cast<uint4 *>(a.rast + t);
-    const uint4 *src = reinterpret_cast<const uint4 *>(&r);
-    dst[0] = src[0];
-    dst[1] = src[1];
-    dst[2] = src[2];
-    dst[3] = src[3];
-    if (r.bx0 <= r.bx1) {
-        float4 *vd = reinterpret_cast<float4 *>(a.vary + (size_t)t * VARY_STRIDE);
+    if (active) {
+        RasterRec r;
+        float vary[VARY_STRIDE];
 #pragma unroll
-        for (int i = 0; i < VARY_STRIDE / 4; i++)
-            vd[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
-        const int32_t tx0 = r.bx0 / TILE_W, tx1 = r.bx1 / TILE_W;
-        const int32_t ty0 = r.by0 / TILE_H, ty1 = r.by1 / TILE_H;
-        for (int32_t ty = ty0; ty <= ty1; ty++)
-            for (int32_t tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tile_count[tile_index(a.frame, tx, ty)], 1u);
+        for (int i = 0; i < VARY_STRIDE; i++) vary[i] = 0.0f;
+        const bool keep = vertex_stage<VS>(a.mesh, a.u, t, r, vary, err);
+        if (keep)
+            finish_raster_rec(r, a.frame);
+        else
+            mark_rejected(r);
+        r.id = t;
+
+        uint4 *dst = reinterpret_cast<uint4 *>(a.rast + t);
+        const uint4 *src = reinterpret_cast<const uint4 *>(&r);
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+        dst[3] = src[3];
+        if (r.bx0 <= r.bx1) {
+            float4 *vd = reinterpret_cast<float4 *>(a.vary + (size_t)t * VARY_STRIDE);
+#pragma unroll
+            for (int i = 0; i < VARY_STRIDE / 4; i++)
+                vd[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
+            tx0 = r.bx0 / TILE_W;
+            ty0 = r.by0 / TILE_H;
+            ntx = r.bx1 / TILE_W - tx0 + 1;
+            cnt = ntx * (r.by1 / TILE_H - ty0 + 1);
+        }
     }
     if (err) atomicOr(a.err, err);
-}
 
-// -----------------------------------------------------------------------------------------
-// k_scan: exclusive scan of tile_count -> tile_offset, one 1024-thread workgroup
-// -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (a.n_tiles + 1023u) / 1024u;
-    const uint32_t begin = min(tid * per, a.n_tiles), end = min(begin + per, a.n_tiles);
-    uint32_t sum = 0;
-    for (uint32_t i = begin; i < end; i++) sum += a.tile_count[i];
-    part[tid] = sum;
+    // Binning.  One lane per polygon would serialise a polygon's atomics (a polygon that spans
+    // 30 tiles = 30 dependent round trips); instead the wave's pairs are numbered by a prefix
+    // sum and dealt round-robin to the lanes, so every lane issues ceil(pairs/64) atomics.
+    int32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t v = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += v;
+    }
+    const int32_t total = __shfl(incl, 63, 64);
+    s_excl[wave][lane] = incl - cnt;
+    s_tx0[wave][lane] = tx0;
+    s_ty0[wave][lane] = ty0;
+    s_ntx[wave][lane] = ntx > 0 ? ntx : 1;
+    s_tri[wave][lane] = t;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t base = part[tid] - sum;
-    for (uint32_t i = begin; i < end; i++) {
-        a.tile_offset[i] = base;
-        base += a.tile_count[i];
-        a.tile_cursor[i] = 0u;
-    }
-    if (tid == 1023u) {
-        a.tile_offset[a.n_tiles] = part[1023];
-        if ((uint64_t)part[1023] > a.capacity) atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
-    }
-}
-
-// -----------------------------------------------------------------------------------------
-// k_fill: scatter polygon ids into the bins (order inside a bin is irrelevant, see header)
-// -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill(FillArgs a)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.n_tri) return;
-    const int4 box = *reinterpret_cast<const int4 *>(&a.rast[t].bx0);  // bx0,bx1,by0,by1
-    if (box.x > box.y) return;
-    const int32_t tx0 = box.x / TILE_W, tx1 = box.y / TILE_W;
-    const int32_t ty0 = box.z / TILE_H, ty1 = box.w / TILE_H;
-    for (int32_t ty = ty0; ty <= ty1; ty++)
-        for (int32_t tx = tx0; tx <= tx1; tx++) {
-            const int32_t tile = tile_index(a.frame, tx, ty);
-            const uint64_t pos = (uint64_t)a.tile_offset[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
-            if (pos < a.capacity) a.bins[pos] = t;
+    for (int32_t p = (int32_t)lane; p < total; p += 64) {
+        // owner = last lane whose exclusive offset is <= p (lanes without pairs share their
+        // successor's offset, so "last" skips them)
+        int32_t lo = 0, hi = 63;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (s_excl[wave][mid] <= p)
+                lo = mid;
+            else
+                hi = mid - 1;
         }
+        const int32_t q = p - s_excl[wave][lo];
+        const int32_t w = s_ntx[wave][lo];
+        const int32_t tile = tile_index(a.frame, s_tx0[wave][lo] + q % w, s_ty0[wave][lo] + q / w);
+        const uint32_t slot = atomicAdd(&a.tile_count[tile], 1u);
+        if (slot < a.bin_cap) {
+            a.bins[(size_t)tile * a.bin_cap + slot] = s_tri[wave][lo];
+        } else {
+            atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
+            atomicMax(a.bin_need, slot + 1u);
+        }
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     constexpr uint32_t PRIOR = DEPTH ? 0u : 0xFFFFFFFFu;
 
     __shared__ __attribute__((aligned(16))) uint64_t s_key[TILE_W * TILE_H];
+    __shared__ uint4 s_rec[CHUNK * 4];  // CHUNK staged RasterRecs
 
     const uint32_t tile = blockIdx.x;
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
@@ -207,8 +210,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     const uint32_t wave = tid >> 6, lane = tid & 63u;
 
     uint32_t n = a.tile_count[tile];
-    const uint32_t start = a.tile_offset[tile];
-    if ((uint64_t)start + n > a.bin_capacity) n = (uint64_t)start < a.bin_capacity ? (uint32_t)(a.bin_capacity - start) : 0u;
+    if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
 
     if (n == 0u && a.fresh) {
         write_cleared_tile<DEPTH>(a, tile_x0, tile_y0);
@@ -235,108 +237,164 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
         }
     }
 
-    // ---- coverage + depth resolve: each wave walks the tile's bin over its own quadrant ---
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t tri = __builtin_amdgcn_readfirstlane(a.bins[start + k]);
-        const RasterRec r = a.rast[tri];
-        const int32_t bx0 = imax(r.bx0, qx0), bx1 = imin(r.bx1, qx0 + QUAD - 1);
-        const int32_t by0 = imax(r.by0, qy0), by1 = imin(r.by1, qy0 + TILE_H - 1);
-        if (bx0 > bx1 || by0 > by1) continue;
-        const Edge e = edge_setup(r);
-        const uint32_t low = DEPTH ? tri + 1u : 0xFFFFFFFEu - tri;
-        const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
-        const int32_t jb0 = (by0 - qy0) >> 3, jb1 = (by1 - qy0) >> 3;
-        for (int32_t jb = jb0; jb <= jb1; jb++) {
-            for (int32_t ib = ib0; ib <= ib1; ib++) {
-                const int32_t px = qx0 + ib * 8 + lx, py = qy0 + jb * 8 + ly;
-                float cx, cy;
-                edge_cross(e, px, py, cx, cy);
-                if (px >= bx0 && px <= bx1 && py >= by0 && py <= by1 && covers(cx, cy, e.cz)) {
-                    const vec3 bar = barycentric(cx, cy, e.cz);
-                    const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                    const uint64_t key = ((uint64_t)depth_order_key(z) << 32) | low;
-                    uint64_t *slot = wkey + (((jb * NBX + ib) << 6) + (int32_t)lane);
-                    if (key > *slot) *slot = key;
+    // ---- coverage + depth resolve ---------------------------------------------------------
+    // The bin is consumed in chunks of CHUNK polygons.  All 256 threads stage a chunk's records
+    // into LDS (thread t fetches 16-byte piece t%4 of polygon t/4: two dependent global loads
+    // for the whole chunk instead of two per polygon per wave); each wave then ballots which
+    // staged polygons touch its quadrant and walks only those, reading the record back from LDS
+    // at a wave-uniform address.
+    const uint32_t *bin = a.bins + (size_t)tile * a.bin_cap;
+    for (uint32_t c0 = 0; c0 < n; c0 += CHUNK) {
+        const uint32_t m = min((uint32_t)CHUNK, n - c0);
+        if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
+        {
+            const uint32_t j = tid >> 2, piece = tid & 3u;
+            if (j < m) {
+                const uint32_t id = bin[c0 + j];
+                s_rec[j * 4u + piece] = reinterpret_cast<const uint4 *>(a.rast + id)[piece];
+            }
+        }
+        __syncthreads();
+
+        bool touch = false;
+        if (lane < m) {
+            const uint4 box = s_rec[lane * 4u];  // bx0 bx1 by0 by1
+            touch = imax((int32_t)box.x, qx0) <= imin((int32_t)box.y, qx0 + QUAD - 1) &&
+                    imax((int32_t)box.z, qy0) <= imin((int32_t)box.w, qy0 + TILE_H - 1);
+        }
+        unsigned long long todo = __ballot(touch);
+        while (todo) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint4 p0 = s_rec[j * 4u + 0u], p1 = s_rec[j * 4u + 1u], p2 = s_rec[j * 4u + 2u];
+            const uint4 p3 = s_rec[j * 4u + 3u];
+            RasterRec r;
+            r.x0 = (int32_t)p1.x; r.y0 = (int32_t)p1.y; r.x1 = (int32_t)p1.z; r.y1 = (int32_t)p1.w;
+            r.x2 = (int32_t)p2.x; r.y2 = (int32_t)p2.y;
+            r.z0 = __uint_as_float(p2.z); r.z1 = __uint_as_float(p2.w); r.z2 = __uint_as_float(p3.x);
+            const uint32_t tri = p3.y;
+            const int32_t bx0 = imax((int32_t)p0.x, qx0), bx1 = imin((int32_t)p0.y, qx0 + QUAD - 1);
+            const int32_t by0 = imax((int32_t)p0.z, qy0), by1 = imin((int32_t)p0.w, qy0 + TILE_H - 1);
+            const Edge e = edge_setup(r);
+            const uint32_t low = DEPTH ? tri + 1u : 0xFFFFFFFEu - tri;
+            const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
+            const int32_t jb0 = (by0 - qy0) >> 3, jb1 = (by1 - qy0) >> 3;
+            for (int32_t jb = jb0; jb <= jb1; jb++) {
+                for (int32_t ib = ib0; ib <= ib1; ib++) {
+                    const int32_t px = qx0 + ib * 8 + lx, py = qy0 + jb * 8 + ly;
+                    float cx, cy;
+                    edge_cross(e, px, py, cx, cy);
+                    if (px >= bx0 && px <= bx1 && py >= by0 && py <= by1 && covers(cx, cy, e.cz)) {
+                        const vec3 bar = barycentric(cx, cy, e.cz);
+                        const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
+                        const uint64_t key = ((uint64_t)depth_order_key(z) << 32) | low;
+                        uint64_t *slot = wkey + (((jb * NBX + ib) << 6) + (int32_t)lane);
+                        if (key > *slot) *slot = key;
+                    }
                 }
             }
         }
     }
 
-    // ---- shade the survivors and stream the tile out, two 32-pixel rows per wave step ------
-    // Lanes are row-major here (lane = x within the row), so depth is stored straight from
-    // registers as whole 128-byte lines and colour is packed to dwords with two lane
-    // permutes.  The vertical flip of get_frame_buffer (scene.rs:92-97) is folded into the
-    // colour address.
+    // ---- shade the survivors and stream the tile out ------------------------------------------
+    // Lanes are row-major here (lane = x within a 32-pixel row, two rows per wave step), so depth
+    // is stored straight from registers as whole 128-byte lines and colour is packed to dwords
+    // with two lane permutes.  The vertical flip of get_frame_buffer (scene.rs:92-97) is folded
+    // into the colour address.  SHADE_G steps are processed together and branch-free (lanes
+    // without a survivor run the same loads on polygon 0 and discard the result) so that the
+    // dependent gathers key -> record -> varyings -> texel of different rows overlap.
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
-    for (int32_t rp = 0; rp < TILE_H / 2; rp++) {
-        const int32_t qy = rp * 2 + hrow;
-        const int32_t px = qx0 + hx, py = qy0 + qy;
-        const bool live = px < W && py >= a.frame.band_y0 && py < a.frame.band_y1;
-        const uint64_t key = wkey[key_slot((uint32_t)hx, (uint32_t)qy)];
-        const uint32_t low = (uint32_t)key;
-        const bool won = live && low != PRIOR;
-
-        uint32_t rgb = 0u;
-        float zout = bits_f32(TR_F32_MIN_BITS);
-        uint32_t tri = NO_WINNER;
-        uint32_t err = 0u;
-        if (won) {
-            tri = DEPTH ? low - 1u : 0xFFFFFFFEu - low;
-            const RasterRec *rr = a.rast + tri;
-            const int4 v0 = *reinterpret_cast<const int4 *>(&rr->x0);    // x0 y0 x1 y1
-            const int4 v1 = *reinterpret_cast<const int4 *>(&rr->x2);    // x2 y2 z0 z1
-            RasterRec r;
-            r.x0 = v0.x; r.y0 = v0.y; r.x1 = v0.z; r.y1 = v0.w;
-            r.x2 = v1.x; r.y2 = v1.y;
-            r.z0 = __int_as_float(v1.z); r.z1 = __int_as_float(v1.w); r.z2 = rr->z2;
-            const Edge e = edge_setup(r);
-            float cx, cy;
-            edge_cross(e, px, py, cx, cy);
-            const vec3 bar = barycentric(cx, cy, e.cz);
-            zout = dot3(bar, make3(r.z0, r.z1, r.z2));
-            if (!DEPTH) {
-                const float4 *vp = reinterpret_cast<const float4 *>(a.vary + (size_t)tri * VARY_STRIDE);
-                float vary[VARY_STRIDE];
-                constexpr int NV = (FS == FS_DARBOUX) ? 6 : 3;
+#pragma unroll 1
+    for (int32_t g = 0; g < TILE_H / 2; g += SHADE_G) {
+        int32_t py[SHADE_G];
+        bool live[SHADE_G], won[SHADE_G];
+        uint32_t tri[SHADE_G], rgb[SHADE_G];
+        float zout[SHADE_G];
+        const int32_t px = qx0 + hx;
+        bool any_won = false;
 #pragma unroll
-                for (int i = 0; i < NV; i++) {
-                    const float4 q = vp[i];
-                    vary[4 * i] = q.x; vary[4 * i + 1] = q.y; vary[4 * i + 2] = q.z; vary[4 * i + 3] = q.w;
-                }
-                rgb = fragment_stage<FS>(a.u, a.tex, vary, bar, (uint32_t)px, (uint32_t)py, zout, a.shadow,
-                                         (uint32_t)W, (uint32_t)H, err);
-            }
-        } else if (live && !a.fresh && !DEPTH) {
-            // untouched pixel of an accumulate render: its colour may share a dword with a
-            // touched neighbour, so fetch it
-            const uint8_t *old = a.fb + ((size_t)(H - 1 - py) * W + px) * 3;
-            rgb = pack_rgb(old[0], old[1], old[2]);
+        for (int u = 0; u < SHADE_G; u++) {
+            const int32_t qy = (g + u) * 2 + hrow;
+            py[u] = qy0 + qy;
+            live[u] = px < W && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+            const uint32_t low = (uint32_t)wkey[key_slot((uint32_t)hx, (uint32_t)qy)];
+            won[u] = live[u] && low != PRIOR;
+            tri[u] = won[u] ? (DEPTH ? low - 1u : 0xFFFFFFFEu - low) : NO_WINNER;
+            rgb[u] = 0u;
+            zout[u] = bits_f32(TR_F32_MIN_BITS);
+            any_won = any_won || won[u];
         }
-        if (err) atomicOr(a.err, err);
+        if (__any(any_won)) {
+            uint32_t err = 0u;
+#pragma unroll
+            for (int u = 0; u < SHADE_G; u++) {
+                const uint32_t ts = won[u] ? tri[u] : 0u;
+                const uint4 *rr = reinterpret_cast<const uint4 *>(a.rast + ts);
+                const uint4 v0 = rr[1];  // x0 y0 x1 y1
+                const uint4 v1 = rr[2];  // x2 y2 z0 z1
+                RasterRec r;
+                r.x0 = (int32_t)v0.x; r.y0 = (int32_t)v0.y; r.x1 = (int32_t)v0.z; r.y1 = (int32_t)v0.w;
+                r.x2 = (int32_t)v1.x; r.y2 = (int32_t)v1.y;
+                r.z0 = __uint_as_float(v1.z); r.z1 = __uint_as_float(v1.w); r.z2 = a.rast[ts].z2;
+                const Edge e = edge_setup(r);
+                float cx, cy;
+                edge_cross(e, px, py[u], cx, cy);
+                const vec3 bar = barycentric(cx, cy, e.cz);
+                const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
+                uint32_t c = 0u, e1 = 0u;
+                if (!DEPTH) {
+                    const float4 *vp = reinterpret_cast<const float4 *>(a.vary + (size_t)ts * VARY_STRIDE);
+                    float vary[VARY_STRIDE];
+                    constexpr int NV = (FS == FS_DARBOUX) ? 6 : 3;
+#pragma unroll
+                    for (int i = 0; i < NV; i++) {
+                        const float4 q = vp[i];
+                        vary[4 * i] = q.x; vary[4 * i + 1] = q.y; vary[4 * i + 2] = q.z; vary[4 * i + 3] = q.w;
+                    }
+                    c = fragment_stage<FS>(a.u, a.tex, vary, bar, (uint32_t)px, (uint32_t)py[u], z, a.shadow,
+                                           (uint32_t)W, (uint32_t)H, e1);
+                }
+                if (won[u]) {
+                    zout[u] = z;
+                    rgb[u] = c;
+                    err |= e1;
+                }
+            }
+            if (err) atomicOr(a.err, err);
+        }
 
-        // depth: only pixels that changed (or every live pixel of a fresh tile)
-        if (live && (won || a.fresh)) depth[(size_t)py * W + px] = zout;
-
-        if (!DEPTH) {
-            if (a.winner && live && (won || a.fresh)) a.winner[(size_t)py * W + px] = tri;
-            uint8_t *row = a.fb + ((size_t)(H - 1 - py) * W + qx0) * 3;
-            if (a.aligned4) {
-                // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3 on,
-                // topped up from pixel p0+1
-                const uint32_t j = (uint32_t)hx;
-                const uint32_t p0 = (4u * j) / 3u, o = (4u * j) % 3u;
-                const uint32_t c0 = (uint32_t)__shfl((int)rgb, (int)(half_base + (p0 & 31u)), 64);
-                const uint32_t c1 = (uint32_t)__shfl((int)rgb, (int)(half_base + ((p0 + 1u) & 31u)), 64);
-                const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
-                const bool row_live = py >= a.frame.band_y0 && py < a.frame.band_y1;
-                if (j < 24u && row_live && (qx0 * 3 + (int32_t)(4u * j)) < W * 3)
-                    *reinterpret_cast<uint32_t *>(row + 4u * j) = dw;
-            } else if (live && (won || a.fresh)) {
-                uint8_t *p = row + 3 * hx;
-                p[0] = (uint8_t)(rgb & 0xFFu);
-                p[1] = (uint8_t)((rgb >> 8) & 0xFFu);
-                p[2] = (uint8_t)((rgb >> 16) & 0xFFu);
+#pragma unroll
+        for (int u = 0; u < SHADE_G; u++) {
+            if (!DEPTH && !a.fresh && live[u] && !won[u]) {
+                // untouched pixel of an accumulate render: its colour may share a dword with a
+                // touched neighbour, so fetch it
+                const uint8_t *old = a.fb + ((size_t)(H - 1 - py[u]) * W + px) * 3;
+                rgb[u] = pack_rgb(old[0], old[1], old[2]);
+            }
+            // depth: only pixels that changed (or every live pixel of a fresh tile)
+            const bool put = live[u] && (won[u] || a.fresh);
+            if (put) depth[(size_t)py[u] * W + px] = zout[u];
+            if (!DEPTH) {
+                if (a.winner && put) a.winner[(size_t)py[u] * W + px] = tri[u];
+                uint8_t *row = a.fb + ((size_t)(H - 1 - py[u]) * W + qx0) * 3;
+                if (a.aligned4) {
+                    // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
+                    // on, topped up from pixel p0+1
+                    const uint32_t j = (uint32_t)hx;
+                    const uint32_t p0 = (4u * j) / 3u, o = (4u * j) % 3u;
+                    const uint32_t c0 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + (p0 & 31u)), 64);
+                    const uint32_t c1 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + ((p0 + 1u) & 31u)), 64);
+                    const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
+                    const bool row_live = py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+                    if (j < 24u && row_live && (qx0 * 3 + (int32_t)(4u * j)) < W * 3)
+                        *reinterpret_cast<uint32_t *>(row + 4u * j) = dw;
+                } else if (put) {
+                    uint8_t *p = row + 3 * hx;
+                    p[0] = (uint8_t)(rgb[u] & 0xFFu);
+                    p[1] = (uint8_t)((rgb[u] >> 8) & 0xFFu);
+                    p[2] = (uint8_t)((rgb[u] >> 16) & 0xFFu);
+                }
             }
         }
     }
@@ -396,21 +454,6 @@ int launch_setup(int vs, const SetupArgs &a, hipStream_t st)
     case VS_DEPTH: hipLaunchKernelGGL(k_setup<VS_DEPTH>, grid, block, 0, st, a); break;
     default: return -1;
     }
-    TR_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_scan(const ScanArgs &a, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
-    TR_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_fill(const FillArgs &a, hipStream_t st)
-{
-    if (a.n_tri == 0) return 0;
-    hipLaunchKernelGGL(k_fill, dim3((a.n_tri + 255u) / 256u), dim3(256), 0, st, a);
     TR_LAUNCH_CHECK();
     return 0;
 }

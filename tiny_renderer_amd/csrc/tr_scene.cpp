@@ -69,8 +69,8 @@ const PipelineDesc kPipelines[P_COUNT] = {
     { "occlusion", 2, { { 1, VS_DEPTH, FS_DEPTH }, { 2, VS_PLAIN, FS_OCCLUSION2 } } },
 };
 
-const char *kKernelNames[] = { "k_setup", "k_scan", "k_fill", "k_tile", "k_tile_depth", "k_clear" };
-enum KernelId { K_SETUP = 0, K_SCAN, K_FILL, K_TILE, K_TILE_DEPTH, K_CLEAR, K_COUNT };
+const char *kKernelNames[] = { "k_setup", "k_tile", "k_tile_depth", "k_clear" };
+enum KernelId { K_SETUP = 0, K_TILE, K_TILE_DEPTH, K_CLEAR, K_COUNT };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -106,9 +106,10 @@ struct tr_scene {
     uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
     RasterRec *d_rast = nullptr;
     float *d_vary = nullptr;
-    uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr;
-    uint32_t *d_bins = nullptr;
-    uint64_t bin_capacity = 0;
+    uint32_t *d_tile_count = nullptr;
+    uint32_t *d_bins = nullptr;  // n_tiles_full x bin_cap polygon ids
+    uint32_t bin_cap = 0;        // per-tile capacity; grown on overflow
+    uint32_t *d_bin_need = nullptr;
     float *d_z = nullptr, *d_shadow = nullptr;
     uint8_t *d_fb = nullptr;
     bool own_fb = false;
@@ -124,6 +125,14 @@ struct tr_scene {
 
     tr_uniforms uniforms = {};
     int host_status = TR_OK;  // sticky failure of the last render's host-side prepare
+
+    // What the last render() started from, so that a frame whose bins overflowed can be
+    // rendered again after the bins have grown.
+    struct {
+        float light[3], from[3], at[3], up[3];
+        bool z_fb_cleared, shadow_cleared;
+        bool valid;
+    } last = {};
 
     bool profiling = false;
     std::vector<EventPair> events;
@@ -230,6 +239,46 @@ int flush_clear_shadow(tr_scene *s)
     return TR_OK;
 }
 
+int render_frame(tr_scene *s);
+
+// A tile received more polygons than its bin holds.  Grow the bins to what the frame asked for
+// and render it again from the state it started in.  That is exact when the frame started from
+// cleared targets (the per-frame protocol of app.rs:170-210); an accumulating render cannot be
+// replayed, so it reports TR_E_BIN_OVERFLOW after growing and the caller clears and renders again.
+int recover_from_overflow(tr_scene *s)
+{
+    uint32_t need = 0;
+    HIP_TRY(hipMemcpy(&need, s->d_bin_need, sizeof need, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(s->d_bin_need, 0, sizeof need));
+    uint64_t cap = s->bin_cap;
+    while (cap < need) cap *= 2;
+    if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
+    if (cap < need || cap * (uint64_t)s->n_tiles_full * 4ull > (64ull << 30))
+        return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 64 GiB");
+    dev_free(s->d_bins);
+    s->bin_cap = (uint32_t)cap;
+    int st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap);
+    if (st != TR_OK) return st;
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
+    if (!replayable)
+        return tr::fail(TR_E_BIN_OVERFLOW,
+                        "triangle bins overflowed during an accumulating render; they have been grown: clear and render again");
+    float keep[12];
+    memcpy(keep, s->light, 12); memcpy(keep + 3, s->from, 12); memcpy(keep + 6, s->at, 12); memcpy(keep + 9, s->up, 12);
+    memcpy(s->light, s->last.light, 12); memcpy(s->from, s->last.from, 12);
+    memcpy(s->at, s->last.at, 12); memcpy(s->up, s->last.up, 12);
+    const bool z_now = s->z_fb_cleared, sh_now = s->shadow_cleared;
+    s->z_fb_cleared = true;
+    s->shadow_cleared = s->last.shadow_cleared;
+    st = render_frame(s);
+    // a clear() issued after the overflowing render stays pending
+    s->z_fb_cleared = s->z_fb_cleared || z_now;
+    s->shadow_cleared = s->shadow_cleared || sh_now;
+    memcpy(s->light, keep, 12); memcpy(s->from, keep + 3, 12); memcpy(s->at, keep + 6, 12); memcpy(s->up, keep + 9, 12);
+    return st;
+}
+
 // Waits for the stream and folds the device error word into a status.
 int sync_and_status(tr_scene *s)
 {
@@ -239,8 +288,14 @@ int sync_and_status(tr_scene *s)
     HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
     if (s->host_status != TR_OK) return s->host_status;
-    if (err & DE_BIN_OVERFLOW)
-        return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins overflowed; raise tr_options.bin_capacity");
+    if (err & DE_BIN_OVERFLOW) {
+        int st = recover_from_overflow(s);
+        if (st != TR_OK) return st;
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
+        if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));
+        if (err & DE_BIN_OVERFLOW) return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins overflowed twice");
+    }
     if (err & (DE_W_ZERO | DE_TEX_OOB | DE_SHADOW_OOB | DE_SINGULAR)) {
         char buf[160];
         snprintf(buf, sizeof buf,
@@ -295,7 +350,6 @@ int run_pass(tr_scene *s, const PassDesc &p)
     }
 
     const DevFrame &frame = depth_pass ? s->frame_full : s->frame;
-    const uint32_t n_tiles = depth_pass ? s->n_tiles_full : s->n_tiles;
 
     SetupArgs sa;
     sa.mesh = s->mesh;
@@ -304,6 +358,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.rast = s->d_rast;
     sa.vary = s->d_vary;
     sa.tile_count = s->d_tile_count;
+    sa.bins = s->d_bins;
+    sa.bin_cap = s->bin_cap;
+    sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
     {
         Timed t(s, K_SETUP);
@@ -311,38 +368,11 @@ int run_pass(tr_scene *s, const PassDesc &p)
         if (rc) return launch_status(rc, "k_setup");
     }
 
-    ScanArgs sc;
-    sc.tile_count = s->d_tile_count;
-    sc.tile_offset = s->d_tile_offset;
-    sc.tile_cursor = s->d_tile_cursor;
-    sc.n_tiles = n_tiles;
-    sc.capacity = s->bin_capacity;
-    sc.err = s->d_err;
-    {
-        Timed t(s, K_SCAN);
-        int rc = launch_scan(sc, s->stream);
-        if (rc) return launch_status(rc, "k_scan");
-    }
-
-    FillArgs fa;
-    fa.rast = s->d_rast;
-    fa.frame = frame;
-    fa.n_tri = s->mesh.n_tri;
-    fa.tile_offset = s->d_tile_offset;
-    fa.tile_cursor = s->d_tile_cursor;
-    fa.bins = s->d_bins;
-    fa.capacity = s->bin_capacity;
-    {
-        Timed t(s, K_FILL);
-        int rc = launch_fill(fa, s->stream);
-        if (rc) return launch_status(rc, "k_fill");
-    }
-
     TileArgs ta;
     ta.rast = s->d_rast;
     ta.vary = s->d_vary;
     ta.bins = s->d_bins;
-    ta.tile_offset = s->d_tile_offset;
+    ta.bin_cap = s->bin_cap;
     ta.tile_count = s->d_tile_count;
     ta.frame = frame;
     ta.u = du;
@@ -352,7 +382,6 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.fb = s->d_fb;
     ta.winner = s->d_winner;
     ta.err = s->d_err;
-    ta.bin_capacity = s->bin_capacity;
     ta.fresh = fresh;
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
@@ -360,6 +389,20 @@ int run_pass(tr_scene *s, const PassDesc &p)
         Timed t(s, depth_pass ? K_TILE_DEPTH : K_TILE);
         int rc = launch_tile(p.fs, ta, s->stream);
         if (rc) return launch_status(rc, "k_tile");
+    }
+    return TR_OK;
+}
+
+int render_frame(tr_scene *s)
+{
+    s->host_status = TR_OK;
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    for (int i = 0; i < pd.n_passes; i++) {
+        int st = run_pass(s, pd.pass[i]);
+        if (st != TR_OK) {
+            s->host_status = st;
+            return st;
+        }
     }
     return TR_OK;
 }
@@ -391,9 +434,8 @@ void destroy(tr_scene *s)
     dev_free(s->d_rast);
     dev_free(s->d_vary);
     dev_free(s->d_tile_count);
-    dev_free(s->d_tile_offset);
-    dev_free(s->d_tile_cursor);
     dev_free(s->d_bins);
+    dev_free(s->d_bin_need);
     dev_free(s->d_z);
     dev_free(s->d_shadow);
     if (s->own_fb) dev_free(s->d_fb);
@@ -502,20 +544,14 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if ((st = dev_alloc(&s->d_rast, (size_t)mesh->n_tri))) return st;
     if ((st = dev_alloc(&s->d_vary, (size_t)mesh->n_tri * VARY_STRIDE))) return st;
     if ((st = dev_alloc(&s->d_tile_count, (size_t)s->n_tiles_full))) return st;
-    if ((st = dev_alloc(&s->d_tile_offset, (size_t)s->n_tiles_full + 1))) return st;
-    if ((st = dev_alloc(&s->d_tile_cursor, (size_t)s->n_tiles_full))) return st;
-    uint64_t cap = o.bin_capacity;
-    if (cap == 0) {
-        cap = (uint64_t)mesh->n_tri * s->n_tiles_full;  // every polygon in every tile
-        const uint64_t cap_max = 64ull << 20;      // 64 Mi entries = 256 MiB of the 288 GB
-        if (cap > cap_max) cap = cap_max;
-    }
-    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    if (cap < 1024) cap = 1024;
-    s->bin_capacity = cap;
-    if ((st = dev_alloc(&s->d_bins, (size_t)cap))) return st;
+    if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
+    uint64_t cap = o.bin_capacity ? o.bin_capacity : 1024;  // per tile; grows on overflow
+    if (cap > mesh->n_tri) cap = mesh->n_tri;                // a bin never holds more than all polygons
+    if (cap < 64) cap = 64;
+    s->bin_cap = (uint32_t)cap;
+    if ((st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap))) return st;
     HIP_TRY(hipMemset(s->d_tile_count, 0, (size_t)s->n_tiles_full * 4));
-    HIP_TRY(hipMemset(s->d_tile_cursor, 0, (size_t)s->n_tiles_full * 4));
+    HIP_TRY(hipMemset(s->d_bin_need, 0, 4));
 
     // render targets; Buffer::new / Scene::new zero-fill them (shader.rs:46-47, scene.rs:71)
     if ((st = dev_alloc(&s->d_z, npx))) return st;
@@ -627,16 +663,14 @@ int tr_scene_render(tr_scene *s)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
     HIP_TRY(hipSetDevice(s->device));
-    s->host_status = TR_OK;
-    const PipelineDesc &pd = kPipelines[s->pipeline];
-    for (int i = 0; i < pd.n_passes; i++) {
-        int st = run_pass(s, pd.pass[i]);
-        if (st != TR_OK) {
-            s->host_status = st;
-            return st;
-        }
-    }
-    return TR_OK;
+    memcpy(s->last.light, s->light, 12);
+    memcpy(s->last.from, s->from, 12);
+    memcpy(s->last.at, s->at, 12);
+    memcpy(s->last.up, s->up, 12);
+    s->last.z_fb_cleared = s->z_fb_cleared;
+    s->last.shadow_cleared = s->shadow_cleared;
+    s->last.valid = true;
+    return render_frame(s);
 }
 
 int tr_scene_sync(tr_scene *s)

@@ -163,7 +163,7 @@ TR_HD void finish_raster_rec(RasterRec &r, const DevFrame &f)
         r.bx0 = 1;
         r.bx1 = 0;
     }
-    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    r.pad[0] = r.pad[1] = 0u;
 }
 
 TR_HD void mark_rejected(RasterRec &r)
@@ -174,7 +174,7 @@ TR_HD void mark_rejected(RasterRec &r)
     r.bx1 = 0;
     r.by0 = 1;
     r.by1 = 0;
-    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    r.pad[0] = r.pad[1] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------

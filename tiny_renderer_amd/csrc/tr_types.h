@@ -53,10 +53,13 @@ constexpr int QUAD = 32;
 // bounding box of scene.rs:233-239.  bx0 > bx1 marks a triangle that draws nothing (culled,
 // off screen, or degenerate: |cross.z| < 1, scene.rs:188-191).
 struct RasterRec {
-    int32_t x0, y0, x1, y1, x2, y2;
-    float z0, z1, z2;
-    int32_t bx0, bx1, by0, by1;
-    uint32_t pad[3];
+    int32_t bx0, bx1, by0, by1;  // 16-byte piece 0: clamped bounding box
+    int32_t x0, y0, x1, y1;      // piece 1
+    int32_t x2, y2;              // piece 2
+    float z0, z1;
+    float z2;                    // piece 3
+    uint32_t id;                 //   polygon index (travels with the record into LDS)
+    uint32_t pad[2];
 };
 static_assert(sizeof(RasterRec) == 64, "RasterRec must be 64 bytes");
 
@@ -113,6 +116,10 @@ enum DevErr : uint32_t {
     DE_BIN_OVERFLOW = 1u << 4
 };
 
+// Triangle bins: tile t owns bins[t*bin_cap .. t*bin_cap + bin_cap).  tile_count[t] is bumped
+// with one atomic per (polygon, tile) pair and may run past bin_cap; entries beyond it are dropped,
+// DE_BIN_OVERFLOW is raised and bin_need records the largest count seen so the host can grow the
+// bins and render the frame again.
 struct SetupArgs {
     DevMesh mesh;
     DevFrame frame;
@@ -120,33 +127,17 @@ struct SetupArgs {
     RasterRec *rast;
     float *vary;
     uint32_t *tile_count;
-    uint32_t *err;
-};
-
-struct ScanArgs {
-    uint32_t *tile_count;
-    uint32_t *tile_offset;  // n_tiles + 1
-    uint32_t *tile_cursor;
-    uint32_t n_tiles;
-    uint64_t capacity;
-    uint32_t *err;
-};
-
-struct FillArgs {
-    const RasterRec *rast;
-    DevFrame frame;
-    uint32_t n_tri;
-    const uint32_t *tile_offset;
-    uint32_t *tile_cursor;
     uint32_t *bins;
-    uint64_t capacity;
+    uint32_t bin_cap;
+    uint32_t *bin_need;
+    uint32_t *err;
 };
 
 struct TileArgs {
     const RasterRec *rast;
     const float *vary;
     const uint32_t *bins;
-    const uint32_t *tile_offset;
+    uint32_t bin_cap;
     uint32_t *tile_count;  // reset to 0 by the tile kernel for the next pass
     DevFrame frame;
     DevUniforms u;
@@ -156,7 +147,6 @@ struct TileArgs {
     uint8_t *fb;        // 3*W*H, row 0 = top (already flipped: scene.rs:92-97 folded in)
     uint32_t *winner;   // W*H or nullptr
     uint32_t *err;
-    uint64_t bin_capacity;
     uint32_t fresh;     // 1: target buffers are logically cleared (scene.rs:128-137 folded in)
     uint32_t aligned16; // 1: width % 16 == 0, cleared rows can be written in 16-byte pieces
     uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
