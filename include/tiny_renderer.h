@@ -61,6 +61,7 @@ typedef struct tr_image_rgb8 {
 } tr_image_rgb8;
 
 #define TR_OPT_WINNER_TAP 0x1u /* keep a per-pixel winning-polygon index (parity tap) */
+#define TR_OPT_TILE_STAMPS 0x2u /* diagnostic: record per-tile start/end clocks of the last pass */
 
 typedef struct tr_options {
     uint32_t struct_size;      /* = sizeof(tr_options) */
@@ -73,8 +74,8 @@ typedef struct tr_options {
     void *stream;              /* hipStream_t to enqueue on; NULL = library-owned stream */
     void *frame_buffer_device; /* device pointer to 3*W*H bytes to render into (e.g. the
                                   all-gather buffer); NULL = library-owned */
-    uint64_t bin_capacity;     /* polygon ids per tile bin; 0 = default (1024); bins grow on
-                                  overflow and the frame is rendered again */
+    uint64_t bin_capacity;     /* polygon records per screen-tile bin; 0 = default (256); bins grow
+                                  on overflow and the frame is rendered again */
 } tr_options;
 
 typedef struct tr_scene tr_scene;
@@ -111,6 +112,10 @@ int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out); /* needs TR_OPT_WINNER
 int tr_scene_sync(tr_scene *s);                 /* wait for queued work; returns frame status */
 void *tr_scene_frame_buffer_device(tr_scene *s); /* 3*W*H bytes, row 0 = top */
 int tr_scene_set_stream(tr_scene *s, void *hip_stream);
+
+/* Diagnostic (TR_OPT_TILE_STAMPS): for each tile of the last colour pass {start, end} in 100 MHz
+ * ticks, polygons in its bin, hardware id.  `out` holds 4 * n_tiles entries; returns n_tiles. */
+int tr_scene_debug_tile_stamps(tr_scene *s, uint64_t *out, uint32_t cap_tiles);
 
 /* Per-kernel device timing with HIP events on the scene's stream (bench roofline leg). */
 typedef struct tr_kernel_time {

@@ -1,0 +1,14 @@
+"""Minimal frame loop for profilers: N frames of one workload, nothing else on the GPU."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tiny_renderer_amd as T
+from bench import find_assets, camera, light
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+pipe = sys.argv[2] if len(sys.argv) > 2 else "phong"
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+adir = find_assets("diablo")
+mesh, texs = T.load_assets(adir) if adir else T.synthetic_scene()
+s = T.Scene(size, size, mesh, texs, pipe)
+for _ in range(frames):
+    s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()
+print("status", s.sync())

@@ -147,8 +147,10 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
         }
 
         float *target = depth ? shadow : zbuf;
-        const uint32_t PRIOR = depth ? 0u : 0xFFFFFFFFu;
-        std::vector<uint64_t> key((size_t)TILE_W * TILE_H);
+        struct Key {
+            uint32_t zk, slot1;
+        };
+        std::vector<Key> key((size_t)TILE_W * TILE_H);
         for (uint32_t tile = 0; tile < f.ntx * f.nty; tile++) {
             const int32_t tile_x0 = (int32_t)(tile % f.ntx) * TILE_W;
             const int32_t tile_y0 = (f.ty_base + (int32_t)(tile / f.ntx)) * TILE_H;
@@ -156,20 +158,19 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
             for (int32_t j = 0; j < TILE_H; j++)
                 for (int32_t i = 0; i < TILE_W; i++) {
                     const int32_t px = tile_x0 + i, py = tile_y0 + j;
-                    uint64_t k = ((uint64_t)depth_order_key(bits_f32(TR_F32_MIN_BITS)) << 32) | PRIOR;
+                    Key k = { depth_order_key(bits_f32(TR_F32_MIN_BITS)), 0u };
                     if (!fresh && px < (int32_t)W && py >= f.band_y0 && py < f.band_y1)
-                        k = ((uint64_t)depth_order_key(target[(size_t)py * W + px]) << 32) | PRIOR;
+                        k.zk = depth_order_key(target[(size_t)py * W + px]);
                     key[(size_t)j * TILE_W + i] = k;
                 }
-            // coverage, reverse order on purpose
-            std::vector<uint32_t> &bin = bins[tile];
-            for (size_t bi = bin.size(); bi-- > 0;) {
+            // coverage; the bin is visited in REVERSE polygon order on purpose
+            std::vector<uint32_t> bin(bins[tile].rbegin(), bins[tile].rend());
+            for (size_t bi = 0; bi < bin.size(); bi++) {
                 const uint32_t tri = bin[bi];
                 const RasterRec &r = rast[tri];
                 const int32_t bx0 = imax(r.bx0, tile_x0), bx1 = imin(r.bx1, tile_x0 + TILE_W - 1);
                 const int32_t by0 = imax(r.by0, tile_y0), by1 = imin(r.by1, tile_y0 + TILE_H - 1);
                 const Edge e = edge_setup(r);
-                const uint32_t low = depth ? tri + 1u : 0xFFFFFFFEu - tri;
                 for (int32_t py = by0; py <= by1; py++)
                     for (int32_t px = bx0; px <= bx1; px++) {
                         float cx, cy;
@@ -177,9 +178,19 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                         if (!covers(cx, cy, e.cz)) continue;
                         const vec3 bar = barycentric(cx, cy, e.cz);
                         const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                        const uint64_t k = ((uint64_t)depth_order_key(z) << 32) | low;
-                        uint64_t &slot = key[(size_t)(py - tile_y0) * TILE_W + (px - tile_x0)];
-                        if (k > slot) slot = k;
+                        const uint32_t zk = depth_order_key(z);
+                        Key &cur = key[(size_t)(py - tile_y0) * TILE_W + (px - tile_x0)];
+                        bool win = zk > cur.zk;
+                        if (zk == cur.zk) {
+                            if (cur.slot1 == 0u)
+                                win = depth;
+                            else
+                                win = depth ? tri > bin[cur.slot1 - 1u] : tri < bin[cur.slot1 - 1u];
+                        }
+                        if (win) {
+                            cur.zk = zk;
+                            cur.slot1 = (uint32_t)bi + 1u;
+                        }
                     }
             }
             // shade + write
@@ -187,13 +198,13 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                 for (int32_t i = 0; i < TILE_W; i++) {
                     const int32_t px = tile_x0 + i, py = tile_y0 + j;
                     if (!(px < (int32_t)W && py >= f.band_y0 && py < f.band_y1)) continue;
-                    const uint32_t low = (uint32_t)key[(size_t)j * TILE_W + i];
-                    const bool won = low != PRIOR;
+                    const uint32_t s1 = key[(size_t)j * TILE_W + i].slot1;
+                    const bool won = s1 != 0u;
                     if (!won && !fresh) continue;
                     float zout = bits_f32(TR_F32_MIN_BITS);
                     uint32_t rgb = 0, tri = 0xFFFFFFFFu;
                     if (won) {
-                        tri = depth ? low - 1u : 0xFFFFFFFEu - low;
+                        tri = bin[s1 - 1u];
                         const RasterRec &r = rast[tri];
                         const Edge e = edge_setup(r);
                         float cx, cy;

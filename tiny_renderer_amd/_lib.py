@@ -20,6 +20,7 @@ TR_E_BIN_OVERFLOW = -9
 TR_E_NOMEM = -10
 
 TR_OPT_WINNER_TAP = 0x1
+TR_OPT_TILE_STAMPS = 0x2
 
 
 class TinyRendererError(RuntimeError):
@@ -75,6 +76,7 @@ SYMBOLS = {
     "tr_scene_sync": (C.c_int, [C.c_void_p]),
     "tr_scene_frame_buffer_device": (C.c_void_p, [C.c_void_p]),
     "tr_scene_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_debug_tile_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "tr_scene_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tr_scene_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int]),
     "tr_pipeline_count": (C.c_int, []),

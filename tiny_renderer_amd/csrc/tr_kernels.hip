@@ -2,20 +2,22 @@
 //
 // The reference (src/scene.rs:151-268) is one serial loop nest: pass x polygon x bbox-x x
 // bbox-y, depth-testing and shading each covered pixel in polygon order.  Here a render pass is
+// two kernels:
 //
-//   k_setup   one thread per polygon: vertex closure, clamped bounding box, then the wavefront
-//             spreads its (polygon, tile) pairs over all 64 lanes and appends polygon ids to
-//             fixed-capacity per-tile bins (one atomic per pair)
-//   k_tile    one 256-thread workgroup per 128x32 screen tile: the bin's records are staged in
-//             LDS, coverage + depth resolve run against LDS keys, then the winners are shaded and
-//             depth and colour are streamed out once
+//   k_setup   one lane per polygon: vertex closure, clamped bounding box; then the wavefront
+//             spreads its (polygon, tile) pairs over all 64 lanes and appends the polygon's
+//             complete record to the fixed-capacity bin of every tile it touches
+//   k_tile    one 256-thread workgroup per 128x16 screen tile: the bin is copied into LDS in one
+//             coalesced sweep, each wave resolves coverage + depth for its 32x16 quadrant against
+//             LDS keys, then the survivors are shaded from the LDS records and depth and colour
+//             are streamed out once, as whole cache lines
 //
 // Equivalence with the serial loop: `z <= zbuf -> reject` in polygon order means the surviving
 // fragment of a pixel is the one with the largest z, ties going to the lowest polygon index, and
 // the frame buffer keeps the colour of the last accepted fragment = that survivor
-// (shader.rs:169-180, scene.rs:259-263).  A 64-bit max over (order(z), ~index) computes the same
-// survivor in any order, so only survivors are shaded.  The depth-only passes use `>=`
-// (shader.rs:703): largest z, ties to the highest index.
+// (shader.rs:169-180, scene.rs:259-263).  A max over (z, index) computes the same survivor in
+// any order, so only survivors are shaded.  The depth-only passes use `>=` (shader.rs:703):
+// largest z, ties to the highest index.
 //
 // No MFMA anywhere: the path is compare/gather/stream work bound by HBM writes.
 #include <hip/hip_runtime.h>
@@ -32,7 +34,6 @@ constexpr int NBY = TILE_H / 8;  // block rows per quadrant
 constexpr int QPIX = QUAD * TILE_H;
 constexpr uint32_t NO_WINNER = 0xFFFFFFFFu;
 constexpr int SHADE_G = 2;  // row pairs shaded together (memory-level parallelism vs registers)
-constexpr int CHUNK = 64;  // polygons staged in LDS per round (256 threads x 16 B)
 
 __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int32_t ty)
 {
@@ -43,41 +44,37 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 // k_setup
 // -----------------------------------------------------------------------------------------
 template <int VS>
-__global__ __launch_bounds__(256) void k_setup(SetupArgs a)
+__global__ __launch_bounds__(64) void k_setup(SetupArgs a)
 {
-    // per-wave table for the pair distribution: exclusive pair offsets and tile ranges
-    __shared__ int32_t s_excl[4][64], s_tx0[4][64], s_ty0[4][64], s_ntx[4][64];
-    __shared__ uint32_t s_tri[4][64];
+    constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
+    __shared__ uint4 s_rec[64 * P];
+    __shared__ int32_t s_excl[64], s_tx0[64], s_ty0[64], s_ntx[64];
 
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const bool active = t < a.mesh.n_tri;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64u + lane;
 
-    int32_t tx0 = 0, ty0 = 0, ntx = 0, cnt = 0;
+    int32_t tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
     uint32_t err = 0;
-    if (active) {
+    if (t < a.mesh.n_tri) {
         RasterRec r;
-        float vary[VARY_STRIDE];
+        float v[VARY_STRIDE];
 #pragma unroll
-        for (int i = 0; i < VARY_STRIDE; i++) vary[i] = 0.0f;
-        const bool keep = vertex_stage<VS>(a.mesh, a.u, t, r, vary, err);
+        for (int i = 0; i < VARY_STRIDE; i++) v[i] = 0.0f;
+        const bool keep = vertex_stage<VS>(a.mesh, a.u, t, r, v, err);
         if (keep)
             finish_raster_rec(r, a.frame);
         else
             mark_rejected(r);
-        r.id = t;
-
-        uint4 *dst = reinterpret_cast<uint4 *>(a.rast + t);
-        const uint4 *src = reinterpret_cast<const uint4 *>(&r);
-        dst[0] = src[0];
-        dst[1] = src[1];
-        dst[2] = src[2];
-        dst[3] = src[3];
         if (r.bx0 <= r.bx1) {
-            float4 *vd = reinterpret_cast<float4 *>(a.vary + (size_t)t * VARY_STRIDE);
+            uint4 *o = s_rec + lane * P;
+            o[0] = make_uint4((uint32_t)r.bx0, (uint32_t)r.bx1, (uint32_t)r.by0, (uint32_t)r.by1);
+            o[1] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, (uint32_t)r.x1, (uint32_t)r.y1);
+            o[2] = make_uint4((uint32_t)r.x2, (uint32_t)r.y2, __float_as_uint(r.z0), __float_as_uint(r.z1));
+            o[3] = make_uint4(__float_as_uint(r.z2), t, __float_as_uint(v[0]), __float_as_uint(v[1]));
 #pragma unroll
-            for (int i = 0; i < VARY_STRIDE / 4; i++)
-                vd[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
+            for (int i = 4; i < P; i++)
+                o[i] = make_uint4(__float_as_uint(v[4 * i - 14]), __float_as_uint(v[4 * i - 13]),
+                                  __float_as_uint(v[4 * i - 12]), __float_as_uint(v[4 * i - 11]));
             tx0 = r.bx0 / TILE_W;
             ty0 = r.by0 / TILE_H;
             ntx = r.bx1 / TILE_W - tx0 + 1;
@@ -86,43 +83,63 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
     }
     if (err) atomicOr(a.err, err);
 
-    // Binning.  One lane per polygon would serialise a polygon's atomics (a polygon that spans
-    // 30 tiles = 30 dependent round trips); instead the wave's pairs are numbered by a prefix
-    // sum and dealt round-robin to the lanes, so every lane issues ceil(pairs/64) atomics.
+    // Binning.  One lane per polygon would serialise a polygon's atomics (a polygon spanning 30
+    // tiles = 30 dependent round trips); instead the wave's (polygon, tile) pairs are numbered by
+    // a prefix sum and dealt round-robin to the lanes, four per lane per trip so that the four
+    // returning atomics are in flight together.
     int32_t incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int32_t v = __shfl_up(incl, d, 64);
-        if ((int)lane >= d) incl += v;
+        const int32_t up = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += up;
     }
     const int32_t total = __shfl(incl, 63, 64);
-    s_excl[wave][lane] = incl - cnt;
-    s_tx0[wave][lane] = tx0;
-    s_ty0[wave][lane] = ty0;
-    s_ntx[wave][lane] = ntx > 0 ? ntx : 1;
-    s_tri[wave][lane] = t;
+    s_excl[lane] = incl - cnt;
+    s_tx0[lane] = tx0;
+    s_ty0[lane] = ty0;
+    s_ntx[lane] = ntx;
     __syncthreads();
-    for (int32_t p = (int32_t)lane; p < total; p += 64) {
-        // owner = last lane whose exclusive offset is <= p (lanes without pairs share their
-        // successor's offset, so "last" skips them)
-        int32_t lo = 0, hi = 63;
+
+    for (int32_t p0 = (int32_t)lane; p0 < total; p0 += 256) {
+        int32_t own[4], tile[4];
+        uint32_t slot[4];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int32_t mid = (lo + hi + 1) >> 1;
-            if (s_excl[wave][mid] <= p)
-                lo = mid;
-            else
-                hi = mid - 1;
+        for (int k = 0; k < 4; k++) {
+            const int32_t p = p0 + 64 * k;
+            own[k] = -1;
+            tile[k] = 0;
+            if (p < total) {
+                // owner = last lane whose exclusive offset is <= p (lanes without pairs share
+                // their successor's offset, so "last" skips them)
+                int32_t lo = 0, hi = 63;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const int32_t mid = (lo + hi + 1) >> 1;
+                    if (s_excl[mid] <= p)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                const int32_t q = p - s_excl[lo], w = s_ntx[lo];
+                own[k] = lo;
+                tile[k] = tile_index(a.frame, s_tx0[lo] + q % w, s_ty0[lo] + q / w);
+            }
         }
-        const int32_t q = p - s_excl[wave][lo];
-        const int32_t w = s_ntx[wave][lo];
-        const int32_t tile = tile_index(a.frame, s_tx0[wave][lo] + q % w, s_ty0[wave][lo] + q / w);
-        const uint32_t slot = atomicAdd(&a.tile_count[tile], 1u);
-        if (slot < a.bin_cap) {
-            a.bins[(size_t)tile * a.bin_cap + slot] = s_tri[wave][lo];
-        } else {
-            atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
-            atomicMax(a.bin_need, slot + 1u);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            slot[k] = own[k] >= 0 ? atomicAdd(&a.tile_count[tile[k]], 1u) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (own[k] < 0) continue;
+            if (slot[k] < a.bin_cap) {
+                uint4 *dst = reinterpret_cast<uint4 *>(a.bins) + ((size_t)tile[k] * a.bin_cap + slot[k]) * P;
+                const uint4 *src = s_rec + own[k] * P;
+#pragma unroll
+                for (int i = 0; i < P; i++) dst[i] = src[i];
+            } else {
+                atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
+                atomicMax(a.bin_need, slot[k] + 1u);
+            }
         }
     }
 }
@@ -130,6 +147,21 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a)
 // -----------------------------------------------------------------------------------------
 // k_tile
 // -----------------------------------------------------------------------------------------
+
+// Bijection on [0, n): odd multiplications and xor-shifts are bijections on [0, 2^bits); values
+// that fall outside [0, n) are walked through the same map again (cycle walking).
+__device__ __forceinline__ uint32_t scatter_tile(uint32_t b, uint32_t n, uint32_t bits)
+{
+    const uint32_t mask = (1u << bits) - 1u, sh = (bits + 1u) >> 1;
+    uint32_t x = b;
+    do {
+        x = (x * 0x9E3779B1u) & mask;
+        x ^= x >> sh;
+        x = (x * 0x85EBCA6Bu) & mask;
+        x ^= x >> sh;
+    } while (x >= n);
+    return x;
+}
 
 // LDS index of pixel (qx, qy) of a quadrant: block-major, so that during coverage lane l of a
 // wave touches slot (block*64 + l): conflict-free 8-byte accesses.
@@ -189,19 +221,29 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
     }
 }
 
+__device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
+{
+    return __builtin_amdgcn_readlane((int)v, (int)lane);
+}
+
 template <int FS>
 __global__ __launch_bounds__(256) void k_tile(TileArgs a)
 {
     constexpr bool DEPTH = (FS == FS_DEPTH);
-    // low word of the key: colour passes prefer the LOWEST polygon index on equal z
-    // (0xFFFFFFFE - index; 0xFFFFFFFF = "what was there before", which wins every tie: the
-    // reference rejects z <= zbuf); depth passes prefer the HIGHEST (index + 1; 0 = before).
-    constexpr uint32_t PRIOR = DEPTH ? 0u : 0xFFFFFFFFu;
+    constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
+    constexpr int NMAX = LDS_REC_BYTES / (P * 16);  // records resident in LDS
 
-    __shared__ __attribute__((aligned(16))) uint64_t s_key[TILE_W * TILE_H];
-    __shared__ uint4 s_rec[CHUNK * 4];  // CHUNK staged RasterRecs
+    // Per pixel: .x = depth_order_key(z) of the best fragment so far, .y = its bin slot + 1
+    // (0 = "what the buffer held before this pass").
+    __shared__ uint2 s_key[TILE_W * TILE_H];
+    __shared__ uint4 s_rec[NMAX * P];
 
-    const uint32_t tile = blockIdx.x;
+    // Blocks are dealt to XCDs / shader engines / CUs round-robin in launch order, each CU
+    // receiving the same number of blocks.  A model in the middle of the screen makes the busy
+    // tiles periodic in any affine function of the row-major tile index, and they pile up on a
+    // subset of the CUs (measured: 104 of 256 CUs received no busy tile).  A bijective hash of the
+    // block index breaks the periodicity (pure placement: any order is correct).
+    const uint32_t tile = scatter_tile(blockIdx.x, a.frame.ntx * a.frame.nty, a.scatter_bits);
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
     const int32_t tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
@@ -212,84 +254,110 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     uint32_t n = a.tile_count[tile];
     if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
 
+    // Diagnostic builds of a scene (TR_OPT_TILE_STAMPS) record when each tile ran; the stamps go
+    // to a buffer of their own and nothing is computed from them.
+    uint64_t t_start = 0;
+    if (a.stamps) t_start = wall_clock64();
+
     if (n == 0u && a.fresh) {
         write_cleared_tile<DEPTH>(a, tile_x0, tile_y0);
+        if (a.stamps && tid == 0u) {
+            a.stamps[4u * tile + 0u] = t_start;
+            a.stamps[4u * tile + 1u] = wall_clock64();
+            a.stamps[4u * tile + 2u] = 0u;
+            a.stamps[4u * tile + 3u] = __smid();
+        }
         return;
     }
 
     float *depth = DEPTH ? a.shadow : a.zbuf;
     const int32_t qx0 = tile_x0 + (int32_t)wave * QUAD, qy0 = tile_y0;
-    uint64_t *wkey = s_key + wave * QPIX;
+    uint2 *wkey = s_key + wave * QPIX;
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+    const uint4 *bin = reinterpret_cast<const uint4 *>(a.bins) + (size_t)tile * a.bin_cap * P;
+    const bool resident = n <= (uint32_t)NMAX;  // the whole bin stays in LDS through shading
 
     // ---- initial keys -------------------------------------------------------------------
     {
-        const uint64_t cleared = ((uint64_t)depth_order_key(bits_f32(TR_F32_MIN_BITS)) << 32) | PRIOR;
+        const uint32_t zmin = depth_order_key(bits_f32(TR_F32_MIN_BITS));
 #pragma unroll
         for (int b = 0; b < NBX * NBY; b++) {
-            uint64_t key = cleared;
+            uint32_t zk = zmin;
             if (!a.fresh) {
                 const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
                 if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
-                    key = ((uint64_t)depth_order_key(depth[(size_t)py * W + px]) << 32) | PRIOR;
+                    zk = depth_order_key(depth[(size_t)py * W + px]);
             }
-            wkey[(b << 6) + lane] = key;
+            wkey[(b << 6) + lane] = make_uint2(zk, 0u);
         }
     }
 
     // ---- coverage + depth resolve ---------------------------------------------------------
-    // The bin is consumed in chunks of CHUNK polygons.  All 256 threads stage a chunk's records
-    // into LDS (thread t fetches 16-byte piece t%4 of polygon t/4: two dependent global loads
-    // for the whole chunk instead of two per polygon per wave); each wave then ballots which
-    // staged polygons touch its quadrant and walks only those, reading the record back from LDS
-    // at a wave-uniform address.
-    const uint32_t *bin = a.bins + (size_t)tile * a.bin_cap;
-    for (uint32_t c0 = 0; c0 < n; c0 += CHUNK) {
-        const uint32_t m = min((uint32_t)CHUNK, n - c0);
+    // The bin (n records of P 16-byte pieces, contiguous) is copied to LDS by all 256 threads,
+    // NMAX records at a time.  Each wave then takes 64 records at a time into registers (lane l
+    // holds the raster part of record l), ballots which of them touch its quadrant and walks
+    // those, broadcasting a record to the scalar registers with v_readlane: no memory access at
+    // all per polygon.
+    for (uint32_t c0 = 0; c0 < n; c0 += NMAX) {
+        const uint32_t m = min((uint32_t)NMAX, n - c0);
         if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
-        {
-            const uint32_t j = tid >> 2, piece = tid & 3u;
-            if (j < m) {
-                const uint32_t id = bin[c0 + j];
-                s_rec[j * 4u + piece] = reinterpret_cast<const uint4 *>(a.rast + id)[piece];
-            }
-        }
+        for (uint32_t q = tid; q < m * P; q += 256u) s_rec[q] = bin[(size_t)c0 * P + q];
         __syncthreads();
 
-        bool touch = false;
-        if (lane < m) {
-            const uint4 box = s_rec[lane * 4u];  // bx0 bx1 by0 by1
-            touch = imax((int32_t)box.x, qx0) <= imin((int32_t)box.y, qx0 + QUAD - 1) &&
-                    imax((int32_t)box.z, qy0) <= imin((int32_t)box.w, qy0 + TILE_H - 1);
-        }
-        unsigned long long todo = __ballot(touch);
-        while (todo) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const uint4 p0 = s_rec[j * 4u + 0u], p1 = s_rec[j * 4u + 1u], p2 = s_rec[j * 4u + 2u];
-            const uint4 p3 = s_rec[j * 4u + 3u];
-            RasterRec r;
-            r.x0 = (int32_t)p1.x; r.y0 = (int32_t)p1.y; r.x1 = (int32_t)p1.z; r.y1 = (int32_t)p1.w;
-            r.x2 = (int32_t)p2.x; r.y2 = (int32_t)p2.y;
-            r.z0 = __uint_as_float(p2.z); r.z1 = __uint_as_float(p2.w); r.z2 = __uint_as_float(p3.x);
-            const uint32_t tri = p3.y;
-            const int32_t bx0 = imax((int32_t)p0.x, qx0), bx1 = imin((int32_t)p0.y, qx0 + QUAD - 1);
-            const int32_t by0 = imax((int32_t)p0.z, qy0), by1 = imin((int32_t)p0.w, qy0 + TILE_H - 1);
-            const Edge e = edge_setup(r);
-            const uint32_t low = DEPTH ? tri + 1u : 0xFFFFFFFEu - tri;
-            const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
-            const int32_t jb0 = (by0 - qy0) >> 3, jb1 = (by1 - qy0) >> 3;
-            for (int32_t jb = jb0; jb <= jb1; jb++) {
-                for (int32_t ib = ib0; ib <= ib1; ib++) {
-                    const int32_t px = qx0 + ib * 8 + lx, py = qy0 + jb * 8 + ly;
-                    float cx, cy;
-                    edge_cross(e, px, py, cx, cy);
-                    if (px >= bx0 && px <= bx1 && py >= by0 && py <= by1 && covers(cx, cy, e.cz)) {
-                        const vec3 bar = barycentric(cx, cy, e.cz);
-                        const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                        const uint64_t key = ((uint64_t)depth_order_key(z) << 32) | low;
-                        uint64_t *slot = wkey + (((jb * NBX + ib) << 6) + (int32_t)lane);
-                        if (key > *slot) *slot = key;
+        for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
+            const uint32_t jj = j0 + lane;
+            uint4 r0 = make_uint4(1u, 0u, 1u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
+            if (jj < m) {
+                r0 = s_rec[jj * P + 0];
+                r1 = s_rec[jj * P + 1];
+                r2 = s_rec[jj * P + 2];
+                r3 = s_rec[jj * P + 3];
+            }
+            const bool touch = imax((int32_t)r0.x, qx0) <= imin((int32_t)r0.y, qx0 + QUAD - 1) &&
+                               imax((int32_t)r0.z, qy0) <= imin((int32_t)r0.w, qy0 + TILE_H - 1);
+            unsigned long long todo = __ballot(touch);
+            while (todo) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                RasterRec r;
+                const int32_t bx0 = imax(bcast(r0.x, l), qx0), bx1 = imin(bcast(r0.y, l), qx0 + QUAD - 1);
+                const int32_t by0 = imax(bcast(r0.z, l), qy0), by1 = imin(bcast(r0.w, l), qy0 + TILE_H - 1);
+                r.x0 = bcast(r1.x, l); r.y0 = bcast(r1.y, l); r.x1 = bcast(r1.z, l); r.y1 = bcast(r1.w, l);
+                r.x2 = bcast(r2.x, l); r.y2 = bcast(r2.y, l);
+                r.z0 = __int_as_float(bcast(r2.z, l)); r.z1 = __int_as_float(bcast(r2.w, l));
+                r.z2 = __int_as_float(bcast(r3.x, l));
+                const uint32_t id = (uint32_t)bcast(r3.y, l);
+                const uint32_t slot1 = c0 + j0 + l + 1u;
+                const Edge e = edge_setup(r);
+                const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
+                const int32_t jb0 = (by0 - qy0) >> 3, jb1 = (by1 - qy0) >> 3;
+                for (int32_t jb = jb0; jb <= jb1; jb++) {
+                    for (int32_t ib = ib0; ib <= ib1; ib++) {
+                        const int32_t px = qx0 + ib * 8 + lx, py = qy0 + jb * 8 + ly;
+                        float cx, cy;
+                        edge_cross(e, px, py, cx, cy);
+                        if (px >= bx0 && px <= bx1 && py >= by0 && py <= by1 && covers(cx, cy, e.cz)) {
+                            const vec3 bar = barycentric(cx, cy, e.cz);
+                            const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
+                            const uint32_t zk = depth_order_key(z);
+                            uint2 *slot = wkey + (((jb * NBX + ib) << 6) + (int32_t)lane);
+                            const uint2 cur = *slot;
+                            bool win = zk > cur.x;
+                            if (zk == cur.x) {
+                                // equal depth: the buffer's previous content beats a colour
+                                // fragment (`z <= zbuf` rejects) and loses to a depth fragment
+                                // (`z >= shadow` accepts); between two fragments of this pass
+                                // the polygon index decides
+                                if (cur.y == 0u) {
+                                    win = DEPTH;
+                                } else {
+                                    const uint32_t cur_id = resident ? s_rec[(cur.y - 1u) * P + 3].y
+                                                                     : bin[(size_t)(cur.y - 1u) * P + 3].y;
+                                    win = DEPTH ? id > cur_id : id < cur_id;
+                                }
+                            }
+                            if (win) *slot = make_uint2(zk, slot1);
+                        }
                     }
                 }
             }
@@ -301,15 +369,15 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     // is stored straight from registers as whole 128-byte lines and colour is packed to dwords
     // with two lane permutes.  The vertical flip of get_frame_buffer (scene.rs:92-97) is folded
     // into the colour address.  SHADE_G steps are processed together and branch-free (lanes
-    // without a survivor run the same loads on polygon 0 and discard the result) so that the
-    // dependent gathers key -> record -> varyings -> texel of different rows overlap.
+    // without a survivor run the same loads on record 0 and discard the result) so that the
+    // record and texel fetches of different rows overlap.
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
 #pragma unroll 1
     for (int32_t g = 0; g < TILE_H / 2; g += SHADE_G) {
         int32_t py[SHADE_G];
         bool live[SHADE_G], won[SHADE_G];
-        uint32_t tri[SHADE_G], rgb[SHADE_G];
+        uint32_t wslot[SHADE_G], tri[SHADE_G], rgb[SHADE_G];
         float zout[SHADE_G];
         const int32_t px = qx0 + hx;
         bool any_won = false;
@@ -318,9 +386,10 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
             const int32_t qy = (g + u) * 2 + hrow;
             py[u] = qy0 + qy;
             live[u] = px < W && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
-            const uint32_t low = (uint32_t)wkey[key_slot((uint32_t)hx, (uint32_t)qy)];
-            won[u] = live[u] && low != PRIOR;
-            tri[u] = won[u] ? (DEPTH ? low - 1u : 0xFFFFFFFEu - low) : NO_WINNER;
+            const uint32_t s1 = wkey[key_slot((uint32_t)hx, (uint32_t)qy)].y;
+            won[u] = live[u] && s1 != 0u;
+            wslot[u] = won[u] ? s1 - 1u : 0u;
+            tri[u] = NO_WINNER;
             rgb[u] = 0u;
             zout[u] = bits_f32(TR_F32_MIN_BITS);
             any_won = any_won || won[u];
@@ -329,14 +398,18 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
             uint32_t err = 0u;
 #pragma unroll
             for (int u = 0; u < SHADE_G; u++) {
-                const uint32_t ts = won[u] ? tri[u] : 0u;
-                const uint4 *rr = reinterpret_cast<const uint4 *>(a.rast + ts);
-                const uint4 v0 = rr[1];  // x0 y0 x1 y1
-                const uint4 v1 = rr[2];  // x2 y2 z0 z1
+                uint4 q[P];
+                if (resident) {
+#pragma unroll
+                    for (int i = 1; i < P; i++) q[i] = s_rec[wslot[u] * P + i];
+                } else {
+#pragma unroll
+                    for (int i = 1; i < P; i++) q[i] = bin[(size_t)wslot[u] * P + i];
+                }
                 RasterRec r;
-                r.x0 = (int32_t)v0.x; r.y0 = (int32_t)v0.y; r.x1 = (int32_t)v0.z; r.y1 = (int32_t)v0.w;
-                r.x2 = (int32_t)v1.x; r.y2 = (int32_t)v1.y;
-                r.z0 = __uint_as_float(v1.z); r.z1 = __uint_as_float(v1.w); r.z2 = a.rast[ts].z2;
+                r.x0 = (int32_t)q[1].x; r.y0 = (int32_t)q[1].y; r.x1 = (int32_t)q[1].z; r.y1 = (int32_t)q[1].w;
+                r.x2 = (int32_t)q[2].x; r.y2 = (int32_t)q[2].y;
+                r.z0 = __uint_as_float(q[2].z); r.z1 = __uint_as_float(q[2].w); r.z2 = __uint_as_float(q[3].x);
                 const Edge e = edge_setup(r);
                 float cx, cy;
                 edge_cross(e, px, py[u], cx, cy);
@@ -344,20 +417,23 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
                 uint32_t c = 0u, e1 = 0u;
                 if (!DEPTH) {
-                    const float4 *vp = reinterpret_cast<const float4 *>(a.vary + (size_t)ts * VARY_STRIDE);
-                    float vary[VARY_STRIDE];
-                    constexpr int NV = (FS == FS_DARBOUX) ? 6 : 3;
+                    float v[VARY_STRIDE];
+                    v[0] = __uint_as_float(q[3].z);
+                    v[1] = __uint_as_float(q[3].w);
 #pragma unroll
-                    for (int i = 0; i < NV; i++) {
-                        const float4 q = vp[i];
-                        vary[4 * i] = q.x; vary[4 * i + 1] = q.y; vary[4 * i + 2] = q.z; vary[4 * i + 3] = q.w;
+                    for (int i = 4; i < P; i++) {
+                        v[4 * i - 14] = __uint_as_float(q[i].x);
+                        v[4 * i - 13] = __uint_as_float(q[i].y);
+                        v[4 * i - 12] = __uint_as_float(q[i].z);
+                        v[4 * i - 11] = __uint_as_float(q[i].w);
                     }
-                    c = fragment_stage<FS>(a.u, a.tex, vary, bar, (uint32_t)px, (uint32_t)py[u], z, a.shadow,
+                    c = fragment_stage<FS>(a.u, a.tex, v, bar, (uint32_t)px, (uint32_t)py[u], z, a.shadow,
                                            (uint32_t)W, (uint32_t)H, e1);
                 }
                 if (won[u]) {
                     zout[u] = z;
                     rgb[u] = c;
+                    tri[u] = q[3].y;
                     err |= e1;
                 }
             }
@@ -401,7 +477,15 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
 
     // the bin is consumed: leave the counter at zero for the next pass / frame
     __syncthreads();
-    if (tid == 0u) a.tile_count[tile] = 0u;
+    if (tid == 0u) {
+        a.tile_count[tile] = 0u;
+        if (a.stamps) {
+            a.stamps[4u * tile + 0u] = t_start;
+            a.stamps[4u * tile + 1u] = wall_clock64();
+            a.stamps[4u * tile + 2u] = n;
+            a.stamps[4u * tile + 3u] = __smid();
+        }
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -442,17 +526,21 @@ __global__ __launch_bounds__(256) void k_depth_view(const float *src, uint8_t *d
         if (e_ != hipSuccess) return (int)e_; \
     } while (0)
 
+int rec_pieces_for_vs(int vs) { return vs == VS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
+int rec_pieces_for_fs(int fs) { return fs == FS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
+
 int launch_setup(int vs, const SetupArgs &a, hipStream_t st)
 {
     if (a.mesh.n_tri == 0) return 0;
-    const dim3 grid((a.mesh.n_tri + 255u) / 256u), block(256);
+    if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
+    const dim3 grid((a.mesh.n_tri + 63u) / 64u), block(64);
     switch (vs) {
     case VS_DEFAULT: hipLaunchKernelGGL(k_setup<VS_DEFAULT>, grid, block, 0, st, a); break;
     case VS_PHONG: hipLaunchKernelGGL(k_setup<VS_PHONG>, grid, block, 0, st, a); break;
     case VS_PLAIN: hipLaunchKernelGGL(k_setup<VS_PLAIN>, grid, block, 0, st, a); break;
     case VS_DARBOUX: hipLaunchKernelGGL(k_setup<VS_DARBOUX>, grid, block, 0, st, a); break;
     case VS_DEPTH: hipLaunchKernelGGL(k_setup<VS_DEPTH>, grid, block, 0, st, a); break;
-    default: return -1;
+    default: return (int)hipErrorInvalidValue;
     }
     TR_LAUNCH_CHECK();
     return 0;
@@ -462,6 +550,7 @@ int launch_tile(int fs, const TileArgs &a, hipStream_t st)
 {
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
+    if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
     const dim3 grid(n_tiles), block(256);
     switch (fs) {
     case FS_DEFAULT: hipLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, a); break;
@@ -472,7 +561,7 @@ int launch_tile(int fs, const TileArgs &a, hipStream_t st)
     case FS_SHADOW2: hipLaunchKernelGGL(k_tile<FS_SHADOW2>, grid, block, 0, st, a); break;
     case FS_OCCLUSION2: hipLaunchKernelGGL(k_tile<FS_OCCLUSION2>, grid, block, 0, st, a); break;
     case FS_DEPTH: hipLaunchKernelGGL(k_tile<FS_DEPTH>, grid, block, 0, st, a); break;
-    default: return -1;
+    default: return (int)hipErrorInvalidValue;
     }
     TR_LAUNCH_CHECK();
     return 0;

@@ -104,17 +104,17 @@ struct tr_scene {
     float *d_pos = nullptr, *d_tex = nullptr, *d_nrm = nullptr;
     uint32_t *d_idx = nullptr;
     uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
-    RasterRec *d_rast = nullptr;
-    float *d_vary = nullptr;
     uint32_t *d_tile_count = nullptr;
-    uint32_t *d_bins = nullptr;  // n_tiles_full x bin_cap polygon ids
-    uint32_t bin_cap = 0;        // per-tile capacity; grown on overflow
+    Piece *d_bins = nullptr;     // n_tiles_full x bin_cap records of rec_pieces x 16 B
+    uint32_t bin_cap = 0;        // records per tile; grown on overflow
+    uint32_t rec_pieces = 0;
     uint32_t *d_bin_need = nullptr;
     float *d_z = nullptr, *d_shadow = nullptr;
     uint8_t *d_fb = nullptr;
     bool own_fb = false;
     uint8_t *d_view = nullptr;  // scratch for get_z_buffer / get_shadow_buffer
     uint32_t *d_winner = nullptr;
+    uint64_t *d_stamps = nullptr;
     uint32_t *d_err = nullptr;
 
     // Lazy clear (scene.rs:128-137): `clear` only records that the targets are logically
@@ -253,11 +253,12 @@ int recover_from_overflow(tr_scene *s)
     uint64_t cap = s->bin_cap;
     while (cap < need) cap *= 2;
     if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
-    if (cap < need || cap * (uint64_t)s->n_tiles_full * 4ull > (64ull << 30))
+    if (cap < need) cap = need;
+    if (cap * (uint64_t)s->n_tiles_full * s->rec_pieces * 16ull > (64ull << 30))
         return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 64 GiB");
     dev_free(s->d_bins);
     s->bin_cap = (uint32_t)cap;
-    int st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap);
+    int st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces);
     if (st != TR_OK) return st;
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
@@ -355,11 +356,10 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.mesh = s->mesh;
     sa.frame = frame;
     sa.u = du;
-    sa.rast = s->d_rast;
-    sa.vary = s->d_vary;
     sa.tile_count = s->d_tile_count;
     sa.bins = s->d_bins;
     sa.bin_cap = s->bin_cap;
+    sa.rec_pieces = s->rec_pieces;
     sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
     {
@@ -369,10 +369,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     }
 
     TileArgs ta;
-    ta.rast = s->d_rast;
-    ta.vary = s->d_vary;
     ta.bins = s->d_bins;
     ta.bin_cap = s->bin_cap;
+    ta.rec_pieces = s->rec_pieces;
     ta.tile_count = s->d_tile_count;
     ta.frame = frame;
     ta.u = du;
@@ -385,6 +384,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.fresh = fresh;
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
+    ta.stamps = depth_pass ? nullptr : s->d_stamps;
+    ta.scatter_bits = 1;
+    while ((1u << ta.scatter_bits) < frame.ntx * frame.nty) ta.scatter_bits++;
     {
         Timed t(s, depth_pass ? K_TILE_DEPTH : K_TILE);
         int rc = launch_tile(p.fs, ta, s->stream);
@@ -431,8 +433,6 @@ void destroy(tr_scene *s)
     dev_free(s->d_nrm);
     dev_free(s->d_idx);
     for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
-    dev_free(s->d_rast);
-    dev_free(s->d_vary);
     dev_free(s->d_tile_count);
     dev_free(s->d_bins);
     dev_free(s->d_bin_need);
@@ -441,6 +441,7 @@ void destroy(tr_scene *s)
     if (s->own_fb) dev_free(s->d_fb);
     dev_free(s->d_view);
     dev_free(s->d_winner);
+    dev_free(s->d_stamps);
     dev_free(s->d_err);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -540,16 +541,15 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         s->tex.h[k] = tex[k].h;
     }
 
-    // per-polygon records and bins
-    if ((st = dev_alloc(&s->d_rast, (size_t)mesh->n_tri))) return st;
-    if ((st = dev_alloc(&s->d_vary, (size_t)mesh->n_tri * VARY_STRIDE))) return st;
+    // bins
     if ((st = dev_alloc(&s->d_tile_count, (size_t)s->n_tiles_full))) return st;
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
-    uint64_t cap = o.bin_capacity ? o.bin_capacity : 1024;  // per tile; grows on overflow
-    if (cap > mesh->n_tri) cap = mesh->n_tri;                // a bin never holds more than all polygons
+    uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
+    if (cap > mesh->n_tri) cap = mesh->n_tri;               // a bin never holds more than all polygons
     if (cap < 64) cap = 64;
     s->bin_cap = (uint32_t)cap;
-    if ((st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap))) return st;
+    s->rec_pieces = (pipe == P_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
+    if ((st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
     HIP_TRY(hipMemset(s->d_tile_count, 0, (size_t)s->n_tiles_full * 4));
     HIP_TRY(hipMemset(s->d_bin_need, 0, 4));
 
@@ -568,6 +568,10 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if (o.flags & TR_OPT_WINNER_TAP) {
         if ((st = dev_alloc(&s->d_winner, npx))) return st;
         HIP_TRY(hipMemset(s->d_winner, 0xFF, npx * 4));
+    }
+    if (o.flags & TR_OPT_TILE_STAMPS) {
+        if ((st = dev_alloc(&s->d_stamps, (size_t)s->n_tiles_full * 4))) return st;
+        HIP_TRY(hipMemset(s->d_stamps, 0, (size_t)s->n_tiles_full * 32));
     }
     if ((st = dev_alloc(&s->d_err, 1))) return st;
     HIP_TRY(hipMemset(s->d_err, 0, 4));
@@ -750,6 +754,17 @@ int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out)
     int st = flush_clear_color(s);
     if (st != TR_OK) return st;
     return read_back(s, out, s->d_winner, (size_t)s->width * s->height * 4);
+}
+
+int tr_scene_debug_tile_stamps(tr_scene *s, uint64_t *out, uint32_t cap_tiles)
+{
+    if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
+    if (!s->d_stamps) return tr::fail(TR_E_INVALID, "scene was created without TR_OPT_TILE_STAMPS");
+    if (cap_tiles < s->n_tiles) return tr::fail(TR_E_INVALID, "buffer too small");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(out, s->d_stamps, (size_t)s->n_tiles * 32, hipMemcpyDeviceToHost));
+    return (int)s->n_tiles;
 }
 
 int tr_scene_profile_enable(tr_scene *s, int on)

@@ -40,30 +40,30 @@ enum FsKind : int {
     FS_COUNT
 };
 
-// Screen tile owned by one 256-thread workgroup: 128 x 32 pixels, four 32 x 32 quadrants (one
-// per wavefront), each quadrant sixteen 8 x 8 lane blocks.  128 px of rgb8 = 384 B = three
+// Screen tile owned by one 256-thread workgroup: 128 x 16 pixels, four 32 x 16 quadrants (one
+// per wavefront), each quadrant eight 8 x 8 lane blocks.  128 px of rgb8 = 384 B = three
 // 128-byte lines, 128 px of f32 depth = 512 B = four lines: every row a tile writes is made of
 // whole cache lines.
 constexpr int TILE_W = 128;
-constexpr int TILE_H = 32;
+constexpr int TILE_H = 16;
 constexpr int QUAD = 32;
 
-// Post-vertex record the coverage loop reads (64 B, fetched with scalar loads).
-// Mirrors Buffer.vertex_t_raster / vertex_z_values (shader.rs:34-35) plus the clamped
-// bounding box of scene.rs:233-239.  bx0 > bx1 marks a triangle that draws nothing (culled,
-// off screen, or degenerate: |cross.z| < 1, scene.rs:188-191).
+// Raster part of a polygon record (64 B).  Mirrors Buffer.vertex_t_raster / vertex_z_values
+// (shader.rs:34-35) plus the clamped bounding box of scene.rs:233-239.  bx0 > bx1 marks a
+// polygon that draws nothing (culled, off screen, or degenerate: |cross.z| < 1,
+// scene.rs:188-191).
 struct RasterRec {
     int32_t bx0, bx1, by0, by1;  // 16-byte piece 0: clamped bounding box
     int32_t x0, y0, x1, y1;      // piece 1
     int32_t x2, y2;              // piece 2
     float z0, z1;
-    float z2;                    // piece 3
-    uint32_t id;                 //   polygon index (travels with the record into LDS)
+    float z2;                    // piece 3 (continued by the first two varyings in a bin record)
+    uint32_t id;                 //   polygon index
     uint32_t pad[2];
 };
 static_assert(sizeof(RasterRec) == 64, "RasterRec must be 64 bytes");
 
-// Varyings gathered by the shading step, 24 floats (96 B) per triangle:
+// Varyings, up to 24 floats per polygon:
 //   [0..5]   vertex_uvs            u0,v0,u1,v1,u2,v2        (shader.rs:33)
 //   [6..8]   vertex_intensities                              (shader.rs:30)      default/phong/shadow
 //   darboux instead keeps, from vertex_t_positions / vertex_t_normals (shader.rs:31-32):
@@ -71,6 +71,17 @@ static_assert(sizeof(RasterRec) == 64, "RasterRec must be 64 bytes");
 //   [9..11]  normalize(tpos * (-1,0,1))    row 1                    (shader.rs:618-623)
 //   [12..20] vertex_t_normals, column major
 constexpr int VARY_STRIDE = 24;
+
+// A bin record = everything a tile needs to know about a polygon, as 16-byte pieces:
+//   0: bx0 bx1 by0 by1 | 1: x0 y0 x1 y1 | 2: x2 y2 z0 z1 | 3: z2 id v0 v1 | 4: v2..v5 | 5: v6..v9
+//   darboux also: 6: v10..v13 | 7: v14..v17 | 8: v18..v21
+struct alignas(16) Piece {
+    uint32_t x, y, z, w;
+};
+constexpr int REC_PIECES_SMALL = 6;  //  96 B
+constexpr int REC_PIECES_LARGE = 9;  // 144 B
+// Records a tile keeps resident in LDS (16 KiB worth); larger bins take the chunked path.
+constexpr int LDS_REC_BYTES = 16384;
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {
@@ -116,7 +127,7 @@ enum DevErr : uint32_t {
     DE_BIN_OVERFLOW = 1u << 4
 };
 
-// Triangle bins: tile t owns bins[t*bin_cap .. t*bin_cap + bin_cap).  tile_count[t] is bumped
+// Triangle bins: tile t owns records [t*bin_cap, (t+1)*bin_cap) of `bins`.  tile_count[t] is bumped
 // with one atomic per (polygon, tile) pair and may run past bin_cap; entries beyond it are dropped,
 // DE_BIN_OVERFLOW is raised and bin_need records the largest count seen so the host can grow the
 // bins and render the frame again.
@@ -124,20 +135,18 @@ struct SetupArgs {
     DevMesh mesh;
     DevFrame frame;
     DevUniforms u;
-    RasterRec *rast;
-    float *vary;
     uint32_t *tile_count;
-    uint32_t *bins;
+    Piece *bins;        // n_tiles x bin_cap records of rec_pieces x 16 B
     uint32_t bin_cap;
+    uint32_t rec_pieces;
     uint32_t *bin_need;
     uint32_t *err;
 };
 
 struct TileArgs {
-    const RasterRec *rast;
-    const float *vary;
-    const uint32_t *bins;
+    const Piece *bins;
     uint32_t bin_cap;
+    uint32_t rec_pieces;
     uint32_t *tile_count;  // reset to 0 by the tile kernel for the next pass
     DevFrame frame;
     DevUniforms u;
@@ -150,6 +159,9 @@ struct TileArgs {
     uint32_t fresh;     // 1: target buffers are logically cleared (scene.rs:128-137 folded in)
     uint32_t aligned16; // 1: width % 16 == 0, cleared rows can be written in 16-byte pieces
     uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
+    uint32_t scatter_bits; // block b renders tile scatter(b): a bijective hash on [0, n_tiles) built on
+                           // [0, 2^scatter_bits) by cycle walking
+    uint64_t *stamps;   // diagnostic only (TR_OPT_TILE_STAMPS): per tile {start, end, polygons, hw id}; else nullptr
 };
 
 }  // namespace tr

@@ -37,7 +37,7 @@ class Scene:
     """
 
     def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
-                 winner_tap=False, band_rows=None, stream=None, frame_buffer_device=None,
+                 winner_tap=False, tile_stamps=False, band_rows=None, stream=None, frame_buffer_device=None,
                  bin_capacity=0):
         L = load_library()
         self.width, self.height = int(width), int(height)
@@ -53,7 +53,7 @@ class Scene:
         o = _lib.Options()
         o.struct_size = C.sizeof(_lib.Options)
         o.device = device
-        o.flags = _lib.TR_OPT_WINNER_TAP if winner_tap else 0
+        o.flags = (_lib.TR_OPT_WINNER_TAP if winner_tap else 0) | (_lib.TR_OPT_TILE_STAMPS if tile_stamps else 0)
         if band_rows is not None:
             o.band_row0, o.band_row1 = int(band_rows[0]), int(band_rows[1])
         o.stream = stream
@@ -130,6 +130,13 @@ class Scene:
 
     def set_stream(self, stream):
         check(load_library().tr_scene_set_stream(self._h, stream))
+
+    def debug_tile_stamps(self):
+        """[n_tiles, 4] uint64: start, end (100 MHz ticks), polygons in the bin, hardware id."""
+        cap = ((self.width + 127) // 128) * ((self.height + 15) // 16)
+        out = np.zeros((cap, 4), np.uint64)
+        n = check(load_library().tr_scene_debug_tile_stamps(self._h, out.ctypes.data, cap))
+        return out[:n]
 
     def profile_enable(self, on=True):
         check(load_library().tr_scene_profile_enable(self._h, 1 if on else 0))
