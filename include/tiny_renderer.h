@@ -114,7 +114,8 @@ void *tr_scene_frame_buffer_device(tr_scene *s); /* 3*W*H bytes, row 0 = top */
 int tr_scene_set_stream(tr_scene *s, void *hip_stream);
 
 /* Diagnostic (TR_OPT_TILE_STAMPS): for each tile of the last colour pass {start, end} in 100 MHz
- * ticks, polygons in its bin, hardware id.  `out` holds 4 * n_tiles entries; returns n_tiles. */
+ * ticks, polygons in its bin, hardware id, {bin staged, coverage done} ticks, 2 spare.  `out`
+ * holds 8 * n_tiles entries; returns n_tiles. */
 int tr_scene_debug_tile_stamps(tr_scene *s, uint64_t *out, uint32_t cap_tiles);
 
 /* Per-kernel device timing with HIP events on the scene's stream (bench roofline leg). */
@@ -126,6 +127,12 @@ typedef struct tr_kernel_time {
 int tr_scene_profile_enable(tr_scene *s, int on);
 /* Fills up to `cap` entries, returns the number of kernels or a negative status. */
 int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap);
+
+/* Device self-test of the arithmetic primitives the kernels substitute for the reference's:
+ * Rust `as` casts (f32 -> u32 / i32 / u8) and x / d through a shared reciprocal.  Inputs and
+ * outputs are host arrays of n elements; div_ref receives the device's plain x / d. */
+int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t n, uint32_t *out_u32,
+                            int32_t *out_i32, uint32_t *out_u8, float *out_div, float *out_div_ref);
 
 /* shader.rs:97-112 registry */
 int tr_pipeline_count(void);

@@ -17,6 +17,7 @@ t0 = st[:, 0].min()
 start, end, n = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, st[:, 2]   # us
 dur = end - start
 busy = n > 0
+stage = (st[:, 4] - st[:, 0]) / 100.0; cover = (st[:, 5] - st[:, 4]) / 100.0; shade = (st[:, 1] - st[:, 5]) / 100.0
 print("tiles", len(st), "busy", int(busy.sum()), "kernel span us %.1f" % end.max())
 print("empty tiles: start median %.1f max %.1f ; dur median %.2f p99 %.2f max %.2f" % (
     np.median(start[~busy]), start[~busy].max(), np.median(dur[~busy]), np.percentile(dur[~busy], 99), dur[~busy].max()))
@@ -30,7 +31,8 @@ for i in order:
 for lo, hi in [(1, 5), (5, 10), (10, 20), (20, 40), (40, 1000)]:
     m = (n >= lo) & (n < hi)
     if m.any():
-        print("  bin %3d..%3d: %4d tiles, dur mean %.1f max %.1f" % (lo, hi, m.sum(), dur[m].mean(), dur[m].max()))
+        print("  bin %3d..%3d: %4d tiles, dur mean %.1f max %.1f | stage %.1f cover %.1f shade+store %.1f" % (
+            lo, hi, m.sum(), dur[m].mean(), dur[m].max(), stage[m].mean(), cover[m].mean(), shade[m].mean()))
 # concurrency: busy tiles resident at time t
 for t in (5, 10, 20, 40, 60, 80, 100, 120, 140):
     print("  t=%3d us: busy resident %4d, empty resident %4d" % (t, int(((start <= t) & (end > t) & busy).sum()), int(((start <= t) & (end > t) & ~busy).sum())))

@@ -171,12 +171,13 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                 const int32_t bx0 = imax(r.bx0, tile_x0), bx1 = imin(r.bx1, tile_x0 + TILE_W - 1);
                 const int32_t by0 = imax(r.by0, tile_y0), by1 = imin(r.by1, tile_y0 + TILE_H - 1);
                 const Edge e = edge_setup(r);
+                const Recip rz = recip_of(e.cz);
                 for (int32_t py = by0; py <= by1; py++)
                     for (int32_t px = bx0; px <= bx1; px++) {
                         float cx, cy;
                         edge_cross(e, px, py, cx, cy);
                         if (!covers(cx, cy, e.cz)) continue;
-                        const vec3 bar = barycentric(cx, cy, e.cz);
+                        const vec3 bar = barycentric_by(cx, cy, rz);
                         const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
                         const uint32_t zk = depth_order_key(z);
                         Key &cur = key[(size_t)(py - tile_y0) * TILE_W + (px - tile_x0)];
@@ -247,3 +248,6 @@ extern "C" int tr_emul_covers(const int32_t raster[6], int32_t px, int32_t py, f
 }
 
 extern "C" uint32_t tr_emul_depth_order_key(float z) { return depth_order_key(z); }
+
+// x / d through the shared-reciprocal division of tr_math.h
+extern "C" float tr_emul_div_by(float x, float d) { return div_by(x, recip_of(d)); }

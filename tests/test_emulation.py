@@ -1,0 +1,79 @@
+"""The GPU algorithm on the CPU: the product's vertex/fragment/coverage functions
+(tiny_renderer_amd/csrc/tr_shaders.h, tr_prepare.cpp, compiled for the host by tests/emul) run
+through the kernels' decomposition -- per-tile bins visited in REVERSE order, max over (z, index),
+shade the survivors -- must reproduce the oracle's serial loop bit for bit.  Catches arithmetic
+and ordering mistakes without a GPU; the GPU tests then only have to confirm the device
+arithmetic."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import emul_bind as E
+from tests import helpers as H
+
+PIPES = ("default", "phong", "normal_map", "specular", "darboux", "shadow", "occlusion")
+
+
+def run_both(W, Hh, mesh, texs, pipe, ca, la):
+    s = O.Scene(W, Hh, mesh, texs, pipe)
+    s.clear()
+    s.set_light_direction(H.light(la))
+    s.set_camera(*H.camera(ca))
+    assert s.render() == 0
+    err, z, sh, fb, win = E.render(W, Hh, mesh, texs, pipe, H.light(la), H.camera(ca))
+    assert err == 0
+    return s, z, sh, fb, win
+
+
+def assert_same(s, z, sh, fb, win, pipe):
+    assert np.array_equal(z.view(np.uint32), s.z_f32().view(np.uint32))
+    assert np.array_equal(win, s.winner_u32())
+    if pipe in ("shadow", "occlusion"):
+        assert np.array_equal(sh.view(np.uint32), s.shadow_f32().view(np.uint32))
+    assert np.array_equal(fb, s.get_frame_buffer())   # exact, powf included: same libm on the host
+
+
+@pytest.mark.parametrize("pipe", PIPES)
+def test_synthetic(synthetic, pipe):
+    mesh, texs = synthetic
+    assert_same(*run_both(400, 300, mesh, texs, pipe, 0.5, -0.8), pipe)
+
+
+@pytest.mark.parametrize("pipe", PIPES)
+def test_diablo_800(diablo, pipe):
+    mesh, texs = diablo
+    assert_same(*run_both(800, 800, mesh, texs, pipe, 0.7, -1.1), pipe)
+
+
+def test_african_head_default(african_head):
+    mesh, texs = african_head
+    assert_same(*run_both(800, 800, mesh, texs, "default", 0.0, 0.0), "default")
+
+
+def test_accumulate_without_clear(small_synthetic):
+    mesh, texs = small_synthetic
+    W, Hh = 200, 150
+    s = O.Scene(W, Hh, mesh, texs, "shadow")
+    s.clear()
+    bufs = None
+    for i, (ca, la) in enumerate([(0.0, 0.0), (0.6, 0.9)]):
+        s.set_light_direction(H.light(la))
+        s.set_camera(*H.camera(ca))
+        assert s.render() == 0
+        err, z, sh, fb, win = E.render(W, Hh, mesh, texs, "shadow", H.light(la), H.camera(ca),
+                                       fresh=1 if i == 0 else 0, bufs=bufs)
+        bufs = (z, sh, fb, win)
+    assert np.array_equal(z.view(np.uint32), s.z_f32().view(np.uint32))
+    assert np.array_equal(sh.view(np.uint32), s.shadow_f32().view(np.uint32))
+    assert np.array_equal(fb, s.get_frame_buffer())
+
+
+def test_bands_reassemble(small_synthetic):
+    mesh, texs = small_synthetic
+    W, Hh = 256, 200
+    s, z, sh, fb, win = run_both(W, Hh, mesh, texs, "phong", 0.3, 0.3)
+    out = np.zeros_like(fb)
+    for r0, r1 in ((0, 37), (37, 120), (120, 200)):
+        _, _, _, part, _ = E.render(W, Hh, mesh, texs, "phong", H.light(0.3), H.camera(0.3), band=(r0, r1))
+        out[r0:r1] = part[r0:r1]
+    assert np.array_equal(out, fb)

@@ -207,3 +207,37 @@ def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
         s.set_camera(*H.camera(1.3))
         s.render()
     assert_parity(gpu, cpu, pipe)
+
+
+def test_device_math_selftest(built):
+    """The instruction-level substitutions on the device: v_cvt_{u32,i32}_f32 as Rust `as` casts
+    and the shared-reciprocal division against the device's own '/' and the host's."""
+    import ctypes as C
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 0.999, -0.999, 254.999, 255.0, 255.5, 256.0, 1e10,
+                        -1e10, 4294967040.0, 4294967296.0, 2147483520.0, 2147483648.0, -2147483648.0, -2147483904.0,
+                        1e-40, -1e-40, 3.5, -3.5], np.float32)
+    x = np.concatenate([special, np.trunc((rng.standard_normal(100000) * 2.0 ** rng.integers(0, 40, 100000)))
+                        .astype(np.float32)])
+    d = np.concatenate([np.ones(special.size, np.float32),
+                        np.trunc(rng.integers(1, 1 << 26, 100000).astype(np.float32)) * rng.choice([-1, 1], 100000)
+                        ]).astype(np.float32)
+    n = x.size
+    u32, i32, u8 = np.zeros(n, np.uint32), np.zeros(n, np.int32), np.zeros(n, np.uint32)
+    dv, dref = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    fp = C.POINTER(C.c_float)
+    T._lib.check(T.load_library().tr_selftest_device_math(0, x.ctypes.data_as(fp), d.ctypes.data_as(fp), n,
+                                                         u32.ctypes.data, i32.ctypes.data, u8.ctypes.data,
+                                                         dv.ctypes.data, dref.ctypes.data))
+    L = O.lib()
+    for k in range(special.size + 2000):
+        assert int(u32[k]) == L.tro_f32_to_u32(float(x[k])), x[k]
+        assert int(i32[k]) == L.tro_f32_to_i32(float(x[k])), x[k]
+        assert int(u8[k]) == L.tro_f32_to_u8(float(x[k])), x[k]
+    fin = np.isfinite(x)
+    with np.errstate(all="ignore"):
+        host = (x / d).astype(np.float32)
+    assert np.array_equal(dref[fin].view(np.uint32), host[fin].view(np.uint32))   # device '/' is IEEE
+    assert np.array_equal(dv[fin].view(np.uint32), host[fin].view(np.uint32))     # shared reciprocal too

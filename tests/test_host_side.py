@@ -1,0 +1,171 @@
+"""Host-side pieces of the product that need no GPU: the C-ABI library loads and exports every
+symbol include/tiny_renderer.h declares, the loaders agree with independent decoders, the
+prepares agree with the oracle, and the synthetic scene / instancing helpers are well formed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+def test_library_exports_every_declared_symbol(built):
+    import tiny_renderer_amd as T
+    from tiny_renderer_amd import _lib
+    hdr = open(os.path.join(H.REPO, "include", "tiny_renderer.h")).read()
+    declared = set(re.findall(r"\b(tr_[a-z0-9_]+)\s*\(", hdr))
+    lib = C.CDLL(T.library_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = T.load_library()
+    assert L.tr_abi_version() == 1
+    names = [L.tr_pipeline_name(i).decode() for i in range(L.tr_pipeline_count())]
+    assert tuple(names) == T.PIPELINES  # shader.rs:100-109
+
+
+def test_scene_creation_fails_loudly_without_a_gpu(built, small_synthetic):
+    import torch
+    import tiny_renderer_amd as T
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    mesh, texs = small_synthetic
+    with pytest.raises(T.TinyRendererError) as e:
+        T.Scene(64, 64, mesh, texs, "phong")
+    assert e.value.code == -6  # TR_E_HIP: no CPU fallback exists
+
+
+def test_obj_loader_matches_python_reader(built):
+    import tiny_renderer_amd as T
+    for name, counts in (("diablo", (2519, 3263, 2519, 5022)), ("african_head", (1258, 1339, 1258, 2492))):
+        d = H.asset_dir(name)
+        if d is None:
+            pytest.skip("reference assets not available")
+        got = T.load_obj(os.path.join(d, "model.obj"))
+        ref = H.load_obj_py(os.path.join(d, "model.obj"))
+        assert (got["pos"].shape[0], got["tex"].shape[0], got["nrm"].shape[0], got["idx"].shape[0]) == counts
+        for k in ("pos", "tex", "nrm", "idx"):
+            assert np.array_equal(got[k], ref[k]), k
+
+
+def test_tga_loader_matches_pil(built):
+    import hashlib
+    import tiny_renderer_amd as T
+    # sha256 of the decoded RGB bytes (PIL, this container)
+    prints = {("diablo", "texture.tga"): "90fe242b874ec5fe", ("diablo", "normal_map.tga"): "b7a91e2d456b12fb",
+              ("diablo", "normal_map_tangent.tga"): "1ef1cb262f58bb9b", ("diablo", "specular_map.tga"): "67f36a6fbfa240de",
+              ("african_head", "texture.tga"): "883953448607a493", ("african_head", "normal_map.tga"): "0d99ece19adc680e",
+              ("african_head", "normal_map_tangent.tga"): "08fd0d67cca56823",
+              ("african_head", "specular_map.tga"): "abcd8711b75c6ed9"}
+    for (name, f), digest in prints.items():
+        d = H.asset_dir(name)
+        if d is None:
+            pytest.skip("reference assets not available")
+        got = T.load_tga(os.path.join(d, f))
+        assert got.shape == (1024, 1024, 3)
+        assert hashlib.sha256(got.tobytes()).hexdigest()[:16] == digest, (name, f)
+        assert np.array_equal(got, H.load_tga_pil(os.path.join(d, f)))
+
+
+def test_tga_variants_roundtrip(built, tmp_path):
+    """Types 2 / 3 / 10 / 11, 8 / 24 / 32 bpp, both origins: written by hand, decoded by the loader."""
+    import tiny_renderer_amd as T
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    img[2, 1:5] = img[2, 1]  # a run for the RLE packets
+
+    def header(typ, bpp, desc):
+        return bytes([0, 0, typ, 0, 0, 0, 0, 0, 0, 0, 0, 0, 7, 0, 5, 0, bpp, desc])
+
+    def rle(rows, bpp):
+        out = bytearray()
+        px = [bytes(p) for row in rows for p in row]
+        i = 0
+        while i < len(px):
+            j = i
+            while j + 1 < len(px) and px[j + 1] == px[i] and j - i < 127:
+                j += 1
+            if j > i:
+                out += bytes([0x80 | (j - i)]) + px[i]
+                i = j + 1
+            else:
+                out += bytes([0]) + px[i]
+                i += 1
+        return bytes(out)
+
+    bgr = img[..., ::-1]
+    bgra = np.concatenate([bgr, np.full((5, 7, 1), 200, np.uint8)], -1)
+    grey = img[..., :1]
+    cases = [(2, 24, 0x00, bgr[::-1].tobytes(), img), (2, 24, 0x20, bgr.tobytes(), img),
+             (2, 32, 0x28, bgra.tobytes(), img), (10, 24, 0x00, rle(bgr[::-1], 3), img),
+             (10, 32, 0x08, rle(bgra[::-1], 4), img), (3, 8, 0x00, grey[::-1].tobytes(), grey.repeat(3, -1)),
+             (11, 8, 0x20, rle(grey, 1), grey.repeat(3, -1))]
+    for k, (typ, bpp, desc, body, want) in enumerate(cases):
+        p = tmp_path / ("t%d.tga" % k)
+        p.write_bytes(header(typ, bpp, desc) + body)
+        assert np.array_equal(T.load_tga(str(p)), want), (typ, bpp, desc)
+    bad = tmp_path / "bad.tga"
+    bad.write_bytes(header(1, 8, 0))
+    with pytest.raises(T.TinyRendererError) as e:
+        T.load_tga(str(bad))
+    assert e.value.code == -8
+    with pytest.raises(T.TinyRendererError) as e:
+        T.load_tga(str(tmp_path / "missing.tga"))
+    assert e.value.code == -7
+
+
+def test_obj_edge_cases(built, tmp_path):
+    import tiny_renderer_amd as T
+    p = tmp_path / "m.obj"
+    p.write_text("# comment\nv 0 0 0\nv 1 0 0 1.0\nv 0 1 0\nv 1 1 0\nvt 0.5 0.25\nvt 0 1 0\nvn 0 0 1\n"
+                 "g grp\nusemtl x\nf 1/1/1 2/2/1 3/1/1 4/2/1\nf -1/-1/-1 -2/-2/-1 -3/-1/-1\n")
+    m = T.load_obj(str(p))
+    assert m["pos"].shape == (4, 3) and m["tex"].shape == (2, 3) and m["idx"].shape == (2, 9)
+    assert list(m["idx"][0]) == [0, 0, 0, 1, 1, 0, 2, 0, 0]      # first three of the quad (scene.rs:224-226)
+    assert list(m["idx"][1]) == [3, 1, 0, 2, 0, 0, 1, 1, 0]      # negative = relative indices
+    assert m["tex"][0, 2] == 0.0
+    q = tmp_path / "pn.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    with pytest.raises(T.TinyRendererError) as e:
+        T.load_obj(str(q))
+    assert e.value.code == -3   # not a PTN polygon: the reference panics at scene.rs:218
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_prepare_matches_oracle(built, kind):
+    """shader.rs:183-279: the product's host prepares against the oracle's, bit for bit."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        ca, la = rng.uniform(-3, 3, 2)
+        cam, lt = H.camera(ca), H.light(la)
+        if trial % 4 == 3:   # general positions, not just the app's orbit
+            cam = (list(rng.uniform(-2, 2, 3)), list(rng.uniform(-0.2, 0.2, 3)), [0.1, 1.0, -0.2])
+            lt = list(rng.uniform(-1, 1, 3))
+        W, Hh = int(rng.integers(16, 5000)), int(rng.integers(16, 5000))
+        uo, up = O.Uniforms(), T._lib.Uniforms()
+        if kind == 2:   # pass 2 inherits shadow_matrix from pass 1
+            O.prepare(1, W, Hh, lt, *cam, uniforms=uo)
+            T.prepare_uniforms(1, W, Hh, lt, *cam, uniforms=up)
+        eo, uo = O.prepare(kind, W, Hh, lt, *cam, uniforms=uo)
+        ep, up = T.prepare_uniforms(kind, W, Hh, lt, *cam, uniforms=up)
+        assert (eo == 0) == (ep == 0)
+        for name, _ in O.Uniforms._fields_:
+            a = np.array(getattr(uo, name), np.float32).view(np.uint32)
+            b = np.array(getattr(up, name), np.float32).view(np.uint32)
+            assert np.array_equal(a, b), (kind, trial, name)
+
+
+def test_synthetic_scene_and_instancing(built):
+    import tiny_renderer_amd as T
+    mesh, texs = T.synthetic_scene()
+    assert mesh["idx"].shape == (5022, 9) and all(t.shape == (1024, 1024, 3) for t in texs)
+    assert mesh["tex"][:, :2].min() >= 0.001 and mesh["tex"][:, :2].max() <= 0.999
+    m2, t2 = T.synthetic_scene()
+    assert np.array_equal(m2["pos"], mesh["pos"]) and np.array_equal(t2[0], texs[0])  # deterministic
+    g = T.instanced_grid(mesh, 8)
+    assert g["idx"].shape == (5022 * 64, 9) and g["pos"].shape[0] == 64 * mesh["pos"].shape[0]
+    assert g["idx"][:, 0::3].max() < g["pos"].shape[0] and np.abs(g["pos"][:, :2]).max() <= 1.0

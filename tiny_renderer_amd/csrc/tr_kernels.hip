@@ -256,16 +256,16 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
 
     // Diagnostic builds of a scene (TR_OPT_TILE_STAMPS) record when each tile ran; the stamps go
     // to a buffer of their own and nothing is computed from them.
-    uint64_t t_start = 0;
+    uint64_t t_start = 0, t_staged = 0;
     if (a.stamps) t_start = wall_clock64();
 
     if (n == 0u && a.fresh) {
         write_cleared_tile<DEPTH>(a, tile_x0, tile_y0);
         if (a.stamps && tid == 0u) {
-            a.stamps[4u * tile + 0u] = t_start;
-            a.stamps[4u * tile + 1u] = wall_clock64();
-            a.stamps[4u * tile + 2u] = 0u;
-            a.stamps[4u * tile + 3u] = __smid();
+            a.stamps[8u * tile + 0u] = t_start;
+            a.stamps[8u * tile + 1u] = wall_clock64();
+            a.stamps[8u * tile + 2u] = 0u;
+            a.stamps[8u * tile + 3u] = __smid();
         }
         return;
     }
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
         if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
         for (uint32_t q = tid; q < m * P; q += 256u) s_rec[q] = bin[(size_t)c0 * P + q];
         __syncthreads();
+        if (a.stamps && c0 == 0u) t_staged = wall_clock64();
 
         for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
             const uint32_t jj = j0 + lane;
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 const uint32_t id = (uint32_t)bcast(r3.y, l);
                 const uint32_t slot1 = c0 + j0 + l + 1u;
                 const Edge e = edge_setup(r);
+                const Recip rz = recip_of(e.cz);  // one IEEE division per polygon visit
                 const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
                 const int32_t jb0 = (by0 - qy0) >> 3, jb1 = (by1 - qy0) >> 3;
                 for (int32_t jb = jb0; jb <= jb1; jb++) {
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                         float cx, cy;
                         edge_cross(e, px, py, cx, cy);
                         if (px >= bx0 && px <= bx1 && py >= by0 && py <= by1 && covers(cx, cy, e.cz)) {
-                            const vec3 bar = barycentric(cx, cy, e.cz);
+                            const vec3 bar = barycentric_by(cx, cy, rz);
                             const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
                             const uint32_t zk = depth_order_key(z);
                             uint2 *slot = wkey + (((jb * NBX + ib) << 6) + (int32_t)lane);
@@ -363,6 +365,9 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
             }
         }
     }
+
+    uint64_t t_covered = 0;
+    if (a.stamps) t_covered = wall_clock64();
 
     // ---- shade the survivors and stream the tile out ------------------------------------------
     // Lanes are row-major here (lane = x within a 32-pixel row, two rows per wave step), so depth
@@ -480,10 +485,12 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     if (tid == 0u) {
         a.tile_count[tile] = 0u;
         if (a.stamps) {
-            a.stamps[4u * tile + 0u] = t_start;
-            a.stamps[4u * tile + 1u] = wall_clock64();
-            a.stamps[4u * tile + 2u] = n;
-            a.stamps[4u * tile + 3u] = __smid();
+            a.stamps[8u * tile + 0u] = t_start;
+            a.stamps[8u * tile + 1u] = wall_clock64();
+            a.stamps[8u * tile + 2u] = n;
+            a.stamps[8u * tile + 3u] = __smid();
+            a.stamps[8u * tile + 4u] = t_staged;
+            a.stamps[8u * tile + 5u] = t_covered;
         }
     }
 }
@@ -512,6 +519,21 @@ __global__ __launch_bounds__(256) void k_depth_view(const float *src, uint8_t *d
         p[1] = v;
         p[2] = v;
     }
+}
+
+// tr_selftest_device_math: the device forms of the casts and of the shared-reciprocal division,
+// applied to caller-chosen operands so the host can compare them with its own.
+__global__ __launch_bounds__(256) void k_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32,
+                                                  int32_t *out_i32, uint32_t *out_u8, float *out_div,
+                                                  float *out_div_ref)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_u32[i] = f32_to_u32(x[i]);
+    out_i32[i] = f32_to_i32(x[i]);
+    out_u8[i] = f32_to_u8(x[i]);
+    out_div[i] = div_by(x[i], recip_of(d[i]));
+    out_div_ref[i] = x[i] / d[i];
 }
 
 }  // namespace
@@ -573,6 +595,16 @@ int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st)
     size_t blocks = (n + 255u) / 256u;
     if (blocks > 8192u) blocks = 8192u;
     hipLaunchKernelGGL(k_fill_u32, dim3((uint32_t)blocks), dim3(256), 0, st, dst, value, n);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
+                    uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_selftest, dim3((n + 255u) / 256u), dim3(256), 0, st, x, d, n, out_u32, out_i32, out_u8,
+                       out_div, out_div_ref);
     TR_LAUNCH_CHECK();
     return 0;
 }

@@ -84,7 +84,29 @@ TR_HD vec3 mul_m3_v3(vec3 c0, vec3 c1, vec3 c2, vec3 v)
     return r;
 }
 
-// Rust `as` casts: truncate toward zero, saturate, NaN -> 0.
+// Rust `as` casts: truncate toward zero, saturate, NaN -> 0.  On gfx950 that is exactly what
+// v_cvt_i32_f32 / v_cvt_u32_f32 do (out-of-range saturates, NaN gives 0); the instructions are
+// named explicitly because a plain C cast of an out-of-range value is undefined.  Checked on the
+// device against the branchy host form by tr_selftest_device_math.
+#if defined(__HIP_DEVICE_COMPILE__)
+TR_HD int32_t f32_to_i32(float v)
+{
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+TR_HD uint32_t f32_to_u32(float v)
+{
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+TR_HD uint32_t f32_to_u8(float v)
+{
+    uint32_t r = f32_to_u32(v);
+    return r < 255u ? r : 255u;
+}
+#else
 TR_HD int32_t f32_to_i32(float v)
 {
     if (!(v == v)) return 0;
@@ -105,6 +127,33 @@ TR_HD uint32_t f32_to_u8(float v)
     if (v >= 255.0f) return 255u;
     if (v <= 0.0f) return 0u;
     return (uint32_t)v;
+}
+#endif
+
+// Correctly rounded x / d for many numerators and one divisor.  y = RN(1/d) comes from one IEEE
+// division; q0 = RN(x*y) is corrected twice with exact FMA residuals (Markstein: with
+// y = RN(1/d) and q faithful, RN(q + (x - d*q)*y) = RN(x/d); the first correction makes q
+// faithful).  5 instructions per quotient instead of the 11 of a full division.  Requires finite
+// operands without overflow/underflow: the coverage loop's are integer valued with |d| >= 1.
+// tests/test_coverage_math.py checks bit equality with '/' on 10^8 adversarial pairs.
+struct Recip {
+    float d, y;
+};
+TR_HD Recip recip_of(float d)
+{
+    Recip r;
+    r.d = d;
+    r.y = 1.0f / d;
+    return r;
+}
+TR_HD float div_by(float x, Recip r)
+{
+    const float q0 = x * r.y;
+    float e = fmaf(-q0, r.d, x);
+    float q = fmaf(e, r.y, q0);
+    e = fmaf(-q, r.d, x);
+    q = fmaf(e, r.y, q);
+    return x == 0.0f ? q0 : q;  // the residual form turns -0/d into +0; the product keeps the sign
 }
 
 // util.rs:7-13 with color_2 = (0,0,0), one channel: (t*c + (1-t)*0.0) as u8.  The second term

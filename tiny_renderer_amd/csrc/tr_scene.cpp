@@ -570,8 +570,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         HIP_TRY(hipMemset(s->d_winner, 0xFF, npx * 4));
     }
     if (o.flags & TR_OPT_TILE_STAMPS) {
-        if ((st = dev_alloc(&s->d_stamps, (size_t)s->n_tiles_full * 4))) return st;
-        HIP_TRY(hipMemset(s->d_stamps, 0, (size_t)s->n_tiles_full * 32));
+        if ((st = dev_alloc(&s->d_stamps, (size_t)s->n_tiles_full * 8))) return st;
+        HIP_TRY(hipMemset(s->d_stamps, 0, (size_t)s->n_tiles_full * 64));
     }
     if ((st = dev_alloc(&s->d_err, 1))) return st;
     HIP_TRY(hipMemset(s->d_err, 0, 4));
@@ -608,6 +608,33 @@ extern "C" {
 int tr_abi_version(void) { return TR_ABI_VERSION; }
 
 const char *tr_last_error(void) { return tr::g_last_error.c_str(); }
+
+int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t n, uint32_t *out_u32,
+                            int32_t *out_i32, uint32_t *out_u8, float *out_div, float *out_div_ref)
+{
+    if (!x || !d || !out_u32 || !out_i32 || !out_u8 || !out_div || !out_div_ref)
+        return tr::fail(TR_E_INVALID, "null argument");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    void *buf[7] = {};
+    int st = TR_OK;
+    for (int i = 0; i < 7 && st == TR_OK; i++)
+        if (hipMalloc(&buf[i], (size_t)(n ? n : 1) * 4) != hipSuccess) st = tr::fail(TR_E_HIP, "hipMalloc failed");
+    if (st == TR_OK && (hipMemcpy(buf[0], x, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(buf[1], d, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess))
+        st = tr::fail(TR_E_HIP, "upload failed");
+    if (st == TR_OK) {
+        int rc = launch_selftest((const float *)buf[0], (const float *)buf[1], n, (uint32_t *)buf[2], (int32_t *)buf[3],
+                                 (uint32_t *)buf[4], (float *)buf[5], (float *)buf[6], nullptr);
+        if (rc || hipDeviceSynchronize() != hipSuccess) st = tr::fail(TR_E_HIP, "self-test kernel failed");
+    }
+    void *outs[5] = { out_u32, out_i32, out_u8, out_div, out_div_ref };
+    for (int i = 0; i < 5 && st == TR_OK; i++)
+        if (hipMemcpy(outs[i], buf[2 + i], (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            st = tr::fail(TR_E_HIP, "download failed");
+    for (int i = 0; i < 7; i++)
+        if (buf[i]) (void)hipFree(buf[i]);
+    return st;
+}
 
 int tr_pipeline_count(void) { return P_COUNT; }
 
@@ -763,7 +790,7 @@ int tr_scene_debug_tile_stamps(tr_scene *s, uint64_t *out, uint32_t cap_tiles)
     if (cap_tiles < s->n_tiles) return tr::fail(TR_E_INVALID, "buffer too small");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(out, s->d_stamps, (size_t)s->n_tiles * 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, s->d_stamps, (size_t)s->n_tiles * 64, hipMemcpyDeviceToHost));
     return (int)s->n_tiles;
 }
 

@@ -211,6 +211,12 @@ TR_HD vec3 barycentric(float cx, float cy, float cz)
     return make3(1.0f - (cx + cy) / cz, cx / cz, cy / cz);
 }
 
+// Same values through the shared-reciprocal division (one polygon, many pixels).
+TR_HD vec3 barycentric_by(float cx, float cy, Recip rz)
+{
+    return make3(1.0f - div_by(cx + cy, rz), div_by(cx, rz), div_by(cy, rz));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fragment stage
 // ---------------------------------------------------------------------------------------------

@@ -80,8 +80,9 @@ struct alignas(16) Piece {
 };
 constexpr int REC_PIECES_SMALL = 6;  //  96 B
 constexpr int REC_PIECES_LARGE = 9;  // 144 B
-// Records a tile keeps resident in LDS (16 KiB worth); larger bins take the chunked path.
-constexpr int LDS_REC_BYTES = 16384;
+// Records a tile keeps resident in LDS (8 KiB worth = 85 / 56 records); larger bins take the
+// chunked path.  With the 16 KiB of keys a workgroup stays under 25 KiB: six fit in a CU's LDS.
+constexpr int LDS_REC_BYTES = 8192;
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {

@@ -132,9 +132,9 @@ class Scene:
         check(load_library().tr_scene_set_stream(self._h, stream))
 
     def debug_tile_stamps(self):
-        """[n_tiles, 4] uint64: start, end (100 MHz ticks), polygons in the bin, hardware id."""
+        """[n_tiles, 8] uint64: start, end (100 MHz ticks), polygons in the bin, hardware id, bin staged, coverage done."""
         cap = ((self.width + 127) // 128) * ((self.height + 15) // 16)
-        out = np.zeros((cap, 4), np.uint64)
+        out = np.zeros((cap, 8), np.uint64)
         n = check(load_library().tr_scene_debug_tile_stamps(self._h, out.ctypes.data, cap))
         return out[:n]
 
