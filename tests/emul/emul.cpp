@@ -148,7 +148,8 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
 
         float *target = depth ? shadow : zbuf;
         struct Key {
-            uint32_t zk, slot1;
+            float z;
+            uint32_t slot1;
         };
         std::vector<Key> key((size_t)TILE_W * TILE_H);
         for (uint32_t tile = 0; tile < f.ntx * f.nty; tile++) {
@@ -158,9 +159,9 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
             for (int32_t j = 0; j < TILE_H; j++)
                 for (int32_t i = 0; i < TILE_W; i++) {
                     const int32_t px = tile_x0 + i, py = tile_y0 + j;
-                    Key k = { depth_order_key(bits_f32(TR_F32_MIN_BITS)), 0u };
+                    Key k = { bits_f32(TR_F32_MIN_BITS), 0u };
                     if (!fresh && px < (int32_t)W && py >= f.band_y0 && py < f.band_y1)
-                        k.zk = depth_order_key(target[(size_t)py * W + px]);
+                        k.z = target[(size_t)py * W + px];
                     key[(size_t)j * TILE_W + i] = k;
                 }
             // coverage; the bin is visited in REVERSE polygon order on purpose
@@ -179,17 +180,16 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                         if (!covers(cx, cy, e.cz)) continue;
                         const vec3 bar = barycentric_by(cx, cy, rz);
                         const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                        const uint32_t zk = depth_order_key(z);
                         Key &cur = key[(size_t)(py - tile_y0) * TILE_W + (px - tile_x0)];
-                        bool win = zk > cur.zk;
-                        if (zk == cur.zk) {
+                        bool win = z > cur.z;
+                        if (z == cur.z) {
                             if (cur.slot1 == 0u)
                                 win = depth;
                             else
                                 win = depth ? tri > bin[cur.slot1 - 1u] : tri < bin[cur.slot1 - 1u];
                         }
                         if (win) {
-                            cur.zk = zk;
+                            cur.z = z;
                             cur.slot1 = (uint32_t)bi + 1u;
                         }
                     }

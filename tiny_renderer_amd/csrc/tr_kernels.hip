@@ -33,7 +33,7 @@ constexpr int NBX = QUAD / 8;    // 8x8 lane blocks per quadrant row
 constexpr int NBY = TILE_H / 8;  // block rows per quadrant
 constexpr int QPIX = QUAD * TILE_H;
 constexpr uint32_t NO_WINNER = 0xFFFFFFFFu;
-constexpr int SHADE_G = 2;  // row pairs shaded together (memory-level parallelism vs registers)
+static_assert(NBY == 2 && TILE_H % 4 == 0, "the pixel-pair code assumes two block rows per quadrant");
 
 __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int32_t ty)
 {
@@ -75,6 +75,9 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
             for (int i = 4; i < P; i++)
                 o[i] = make_uint4(__float_as_uint(v[4 * i - 14]), __float_as_uint(v[4 * i - 13]),
                                   __float_as_uint(v[4 * i - 12]), __float_as_uint(v[4 * i - 11]));
+            // spare last word (varying 9 / 21 is unused): RN(1 / cross.z), the one IEEE division
+            // per polygon; k_tile derives every per-pixel quotient from it (tr_math.h div_by)
+            o[P - 1].w = __float_as_uint(record_recip(r));
             tx0 = r.bx0 / TILE_W;
             ty0 = r.by0 / TILE_H;
             ntx = r.bx1 / TILE_W - tx0 + 1;
@@ -131,6 +134,8 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (own[k] < 0) continue;
+            // first record of this tile: put the tile on the busy list, which k_tile runs first
+            if (slot[k] == 0u) a.busy_list[atomicAdd(a.busy_n, 1u)] = (uint32_t)tile[k];
             if (slot[k] < a.bin_cap) {
                 uint4 *dst = reinterpret_cast<uint4 *>(a.bins) + ((size_t)tile[k] * a.bin_cap + slot[k]) * P;
                 const uint4 *src = s_rec + own[k] * P;
@@ -233,42 +238,51 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     constexpr int NMAX = LDS_REC_BYTES / (P * 16);  // records resident in LDS
 
-    // Per pixel: .x = depth_order_key(z) of the best fragment so far, .y = its bin slot + 1
-    // (0 = "what the buffer held before this pass").
+    // Per pixel: .x = z of the best fragment so far (f32 bits; compared as floats, so -0.0 and
+    // +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what the
+    // buffer held before this pass").
     __shared__ uint2 s_key[TILE_W * TILE_H];
     __shared__ uint4 s_rec[NMAX * P];
 
-    // Blocks are dealt to XCDs / shader engines / CUs round-robin in launch order, each CU
-    // receiving the same number of blocks.  A model in the middle of the screen makes the busy
-    // tiles periodic in any affine function of the row-major tile index, and they pile up on a
-    // subset of the CUs (measured: 104 of 256 CUs received no busy tile).  A bijective hash of the
-    // block index breaks the periodicity (pure placement: any order is correct).
-    const uint32_t tile = scatter_tile(blockIdx.x, a.frame.ntx * a.frame.nty, a.scatter_bits);
+    // The launch has 2 * n_tiles blocks.
+    //   * Blocks [0, n_busy) run the list k_setup built of tiles with at least one polygon: the
+    //     long, VALU-bound ones.  They come first so that the machine is full of them from the
+    //     first microsecond (a row-major walk meets the last busy tile at its very end).
+    //   * Blocks [n_tiles, 2 n_tiles) are the "sweep": every tile is visited once in a hashed
+    //     order (neighbouring tiles scattered over the launch); the sweep streams the cleared
+    //     value of the empty tiles -- short, HBM-bound work -- and zeroes the ping-pong counters
+    //     for the next pass.
+    // Measured alternatives (profiles/r01_notes.md): interleaving the two kinds, or letting the
+    // busy blocks issue the sweep stores themselves, was 5-10 % slower.  Any order is correct.
+    const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x >= n_tiles) {
+        const uint32_t i = blockIdx.x - n_tiles;
+        const uint32_t t = scatter_tile(i, n_tiles, a.scatter_bits);
+        if (tid == 0u) {
+            a.tile_count_next[t] = 0u;
+            if (i == 0u) *a.busy_n_next = 0u;
+        }
+        if (a.tile_count[t] == 0u && a.fresh)
+            write_cleared_tile<DEPTH>(a, (int32_t)(t % a.frame.ntx) * TILE_W,
+                                      (a.frame.ty_base + (int32_t)(t / a.frame.ntx)) * TILE_H);
+        return;
+    }
+    if (blockIdx.x >= *a.busy_n) return;
+
+    const uint32_t tile = a.busy_list[blockIdx.x];
+    uint32_t n = a.tile_count[tile];
+    if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
     const int32_t tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
     const int32_t W = (int32_t)a.frame.width, H = (int32_t)a.frame.height;
-    const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
 
-    uint32_t n = a.tile_count[tile];
-    if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
-
-    // Diagnostic builds of a scene (TR_OPT_TILE_STAMPS) record when each tile ran; the stamps go
-    // to a buffer of their own and nothing is computed from them.
+    // Diagnostic builds of a scene (TR_OPT_TILE_STAMPS) record when each busy tile ran; the stamps
+    // go to a buffer of their own and nothing is computed from them.
     uint64_t t_start = 0, t_staged = 0;
     if (a.stamps) t_start = wall_clock64();
-
-    if (n == 0u && a.fresh) {
-        write_cleared_tile<DEPTH>(a, tile_x0, tile_y0);
-        if (a.stamps && tid == 0u) {
-            a.stamps[8u * tile + 0u] = t_start;
-            a.stamps[8u * tile + 1u] = wall_clock64();
-            a.stamps[8u * tile + 2u] = 0u;
-            a.stamps[8u * tile + 3u] = __smid();
-        }
-        return;
-    }
 
     float *depth = DEPTH ? a.shadow : a.zbuf;
     const int32_t qx0 = tile_x0 + (int32_t)wave * QUAD, qy0 = tile_y0;
@@ -279,16 +293,15 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
 
     // ---- initial keys -------------------------------------------------------------------
     {
-        const uint32_t zmin = depth_order_key(bits_f32(TR_F32_MIN_BITS));
 #pragma unroll
         for (int b = 0; b < NBX * NBY; b++) {
-            uint32_t zk = zmin;
+            uint32_t zb = TR_F32_MIN_BITS;
             if (!a.fresh) {
                 const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
                 if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
-                    zk = depth_order_key(depth[(size_t)py * W + px]);
+                    zb = __float_as_uint(depth[(size_t)py * W + px]);
             }
-            wkey[(b << 6) + lane] = make_uint2(zk, 0u);
+            wkey[(b << 6) + lane] = make_uint2(zb, 0u);
         }
     }
 
@@ -308,11 +321,13 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
         for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
             const uint32_t jj = j0 + lane;
             uint4 r0 = make_uint4(1u, 0u, 1u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
+            uint32_t ry = 0u;
             if (jj < m) {
                 r0 = s_rec[jj * P + 0];
                 r1 = s_rec[jj * P + 1];
                 r2 = s_rec[jj * P + 2];
                 r3 = s_rec[jj * P + 3];
+                ry = s_rec[jj * P + (P - 1)].w;
             }
             const bool touch = imax((int32_t)r0.x, qx0) <= imin((int32_t)r0.y, qx0 + QUAD - 1) &&
                                imax((int32_t)r0.z, qy0) <= imin((int32_t)r0.w, qy0 + TILE_H - 1);
@@ -320,32 +335,47 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
             while (todo) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                RasterRec r;
                 const int32_t bx0 = imax(bcast(r0.x, l), qx0), bx1 = imin(bcast(r0.y, l), qx0 + QUAD - 1);
                 const int32_t by0 = imax(bcast(r0.z, l), qy0), by1 = imin(bcast(r0.w, l), qy0 + TILE_H - 1);
-                r.x0 = bcast(r1.x, l); r.y0 = bcast(r1.y, l); r.x1 = bcast(r1.z, l); r.y1 = bcast(r1.w, l);
-                r.x2 = bcast(r2.x, l); r.y2 = bcast(r2.y, l);
-                r.z0 = __int_as_float(bcast(r2.z, l)); r.z1 = __int_as_float(bcast(r2.w, l));
-                r.z2 = __int_as_float(bcast(r3.x, l));
+                const int32_t x0 = bcast(r1.x, l), y0 = bcast(r1.y, l), x1 = bcast(r1.z, l), y1 = bcast(r1.w, l);
+                const int32_t x2 = bcast(r2.x, l), y2 = bcast(r2.y, l);
+                const float z0 = __int_as_float(bcast(r2.z, l)), z1 = __int_as_float(bcast(r2.w, l));
+                const float z2 = __int_as_float(bcast(r3.x, l));
                 const uint32_t id = (uint32_t)bcast(r3.y, l);
                 const uint32_t slot1 = c0 + j0 + l + 1u;
-                const Edge e = edge_setup(r);
-                const Recip rz = recip_of(e.cz);  // one IEEE division per polygon visit
+                // the polygon's part of to_barycentric_coord (scene.rs:178-187), for both rows
+                Edge2 e;
+                e.a0 = splat2((float)isub(x1, x0));
+                e.a1 = splat2((float)isub(x2, x0));
+                e.b0 = splat2((float)isub(y1, y0));
+                e.b1 = splat2((float)isub(y2, y0));
+                e.cz = e.a0 * e.b1 - e.a1 * e.b0;
+                e.y = splat2(__int_as_float(bcast(ry, l)));
+                const float cz = e.cz.x;
+                // this lane's two pixels: (px, pya) in block row 0 and (px, pyb) in block row 1
+                const int32_t pya = qy0 + ly, pyb = qy0 + 8 + ly;
+                const f2 b2 = mk2((float)isub(y0, pya), (float)isub(y0, pyb));
+                const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
                 const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
-                const int32_t jb0 = (by0 - qy0) >> 3, jb1 = (by1 - qy0) >> 3;
-                for (int32_t jb = jb0; jb <= jb1; jb++) {
-                    for (int32_t ib = ib0; ib <= ib1; ib++) {
-                        const int32_t px = qx0 + ib * 8 + lx, py = qy0 + jb * 8 + ly;
-                        float cx, cy;
-                        edge_cross(e, px, py, cx, cy);
-                        if (px >= bx0 && px <= bx1 && py >= by0 && py <= by1 && covers(cx, cy, e.cz)) {
-                            const vec3 bar = barycentric_by(cx, cy, rz);
-                            const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                            const uint32_t zk = depth_order_key(z);
-                            uint2 *slot = wkey + (((jb * NBX + ib) << 6) + (int32_t)lane);
+                for (int32_t ib = ib0; ib <= ib1; ib++) {
+                    const int32_t px = qx0 + ib * 8 + lx;
+                    const bool inx = px >= bx0 && px <= bx1;
+                    f2 cx, cy;
+                    edge_cross2(e, splat2((float)isub(x0, px)), b2, cx, cy);
+                    const bool hita = inx && rowa && covers(cx.x, cy.x, cz);
+                    const bool hitb = inx && rowb && covers(cx.y, cy.y, cz);
+                    if (hita || hitb) {
+                        const Bary2 bar = barycentric2(cx, cy, e);
+                        const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (!(h == 0 ? hita : hitb)) continue;
+                            const float zf = h == 0 ? z.x : z.y;
+                            uint2 *slot = wkey + (((h * NBX + ib) << 6) + (int32_t)lane);
                             const uint2 cur = *slot;
-                            bool win = zk > cur.x;
-                            if (zk == cur.x) {
+                            const float zc = __uint_as_float(cur.x);
+                            bool win = zf > zc;
+                            if (zf == zc) {
                                 // equal depth: the buffer's previous content beats a colour
                                 // fragment (`z <= zbuf` rejects) and loses to a depth fragment
                                 // (`z >= shadow` accepts); between two fragments of this pass
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                                     win = DEPTH ? id > cur_id : id < cur_id;
                                 }
                             }
-                            if (win) *slot = make_uint2(zk, slot1);
+                            if (win) *slot = make_uint2(__float_as_uint(zf), slot1);
                         }
                     }
                 }
@@ -370,25 +400,24 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     if (a.stamps) t_covered = wall_clock64();
 
     // ---- shade the survivors and stream the tile out ------------------------------------------
-    // Lanes are row-major here (lane = x within a 32-pixel row, two rows per wave step), so depth
-    // is stored straight from registers as whole 128-byte lines and colour is packed to dwords
-    // with two lane permutes.  The vertical flip of get_frame_buffer (scene.rs:92-97) is folded
-    // into the colour address.  SHADE_G steps are processed together and branch-free (lanes
-    // without a survivor run the same loads on record 0 and discard the result) so that the
-    // record and texel fetches of different rows overlap.
+    // Lanes are row-major here: lane = x within a 32-pixel row; a step covers four rows, each
+    // lane carrying the two pixels (x, 4s + half) and (x, 4s + 2 + half) through packed
+    // arithmetic.  Depth goes out straight from registers as whole 128-byte lines and colour is
+    // packed to dwords with two lane permutes; the vertical flip of get_frame_buffer
+    // (scene.rs:92-97) is folded into the colour address.  Lanes without a survivor run the same
+    // loads on record 0 and discard the result, so the code is branch-free inside a step.
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
+    const int32_t px = qx0 + hx;
 #pragma unroll 1
-    for (int32_t g = 0; g < TILE_H / 2; g += SHADE_G) {
-        int32_t py[SHADE_G];
-        bool live[SHADE_G], won[SHADE_G];
-        uint32_t wslot[SHADE_G], tri[SHADE_G], rgb[SHADE_G];
-        float zout[SHADE_G];
-        const int32_t px = qx0 + hx;
-        bool any_won = false;
+    for (int32_t sstep = 0; sstep < TILE_H / 4; sstep++) {
+        int32_t py[2];
+        bool live[2], won[2];
+        uint32_t wslot[2], tri[2], rgb[2];
+        float zout[2];
 #pragma unroll
-        for (int u = 0; u < SHADE_G; u++) {
-            const int32_t qy = (g + u) * 2 + hrow;
+        for (int u = 0; u < 2; u++) {
+            const int32_t qy = sstep * 4 + u * 2 + hrow;
             py[u] = qy0 + qy;
             live[u] = px < W && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
             const uint32_t s1 = wkey[key_slot((uint32_t)hx, (uint32_t)qy)].y;
@@ -397,56 +426,98 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
             tri[u] = NO_WINNER;
             rgb[u] = 0u;
             zout[u] = bits_f32(TR_F32_MIN_BITS);
-            any_won = any_won || won[u];
         }
-        if (__any(any_won)) {
-            uint32_t err = 0u;
+        if (__any(won[0] || won[1])) {
+            uint4 qa[P], qb[P];
+            if (resident) {
 #pragma unroll
-            for (int u = 0; u < SHADE_G; u++) {
-                uint4 q[P];
-                if (resident) {
-#pragma unroll
-                    for (int i = 1; i < P; i++) q[i] = s_rec[wslot[u] * P + i];
-                } else {
-#pragma unroll
-                    for (int i = 1; i < P; i++) q[i] = bin[(size_t)wslot[u] * P + i];
+                for (int i = 1; i < P; i++) {
+                    qa[i] = s_rec[wslot[0] * P + i];
+                    qb[i] = s_rec[wslot[1] * P + i];
                 }
-                RasterRec r;
-                r.x0 = (int32_t)q[1].x; r.y0 = (int32_t)q[1].y; r.x1 = (int32_t)q[1].z; r.y1 = (int32_t)q[1].w;
-                r.x2 = (int32_t)q[2].x; r.y2 = (int32_t)q[2].y;
-                r.z0 = __uint_as_float(q[2].z); r.z1 = __uint_as_float(q[2].w); r.z2 = __uint_as_float(q[3].x);
-                const Edge e = edge_setup(r);
-                float cx, cy;
-                edge_cross(e, px, py[u], cx, cy);
-                const vec3 bar = barycentric(cx, cy, e.cz);
-                const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                uint32_t c = 0u, e1 = 0u;
-                if (!DEPTH) {
-                    float v[VARY_STRIDE];
-                    v[0] = __uint_as_float(q[3].z);
-                    v[1] = __uint_as_float(q[3].w);
+            } else {
+#pragma unroll
+                for (int i = 1; i < P; i++) {
+                    qa[i] = bin[(size_t)wslot[0] * P + i];
+                    qb[i] = bin[(size_t)wslot[1] * P + i];
+                }
+            }
+            // to_barycentric_coord for both pixels (each against its own polygon)
+            Edge2 e;
+            e.a0 = mk2((float)isub((int32_t)qa[1].z, (int32_t)qa[1].x), (float)isub((int32_t)qb[1].z, (int32_t)qb[1].x));
+            e.a1 = mk2((float)isub((int32_t)qa[2].x, (int32_t)qa[1].x), (float)isub((int32_t)qb[2].x, (int32_t)qb[1].x));
+            e.b0 = mk2((float)isub((int32_t)qa[1].w, (int32_t)qa[1].y), (float)isub((int32_t)qb[1].w, (int32_t)qb[1].y));
+            e.b1 = mk2((float)isub((int32_t)qa[2].y, (int32_t)qa[1].y), (float)isub((int32_t)qb[2].y, (int32_t)qb[1].y));
+            e.cz = e.a0 * e.b1 - e.a1 * e.b0;
+            e.y = mk2(__uint_as_float(qa[P - 1].w), __uint_as_float(qb[P - 1].w));
+            const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));
+            const f2 b2 = mk2((float)isub((int32_t)qa[1].y, py[0]), (float)isub((int32_t)qb[1].y, py[1]));
+            f2 cx, cy;
+            edge_cross2(e, a2, b2, cx, cy);
+            const Bary2 bar = barycentric2(cx, cy, e);
+            const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
+                                mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
+                                mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
+            uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
+            if (!DEPTH) {
+                // uv = vertex_uvs * bar (2x3 gemv), both pixels
+                f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
+                f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
+                uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
+                vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
+                uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
+                vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
+                if (FS == FS_DEFAULT || FS == FS_PHONG) {
+                    // shader.rs:318-333 / 386-401: texel, diffuse coefficient, color_blend
+                    const uint32_t ta = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
+                    const uint32_t tb = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
+                    const f2 i0 = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
+                    f2 t = i0;
+                    if (FS == FS_PHONG)
+                        t = dot3_2(bar.x, bar.y, bar.z, i0, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
+                                   mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
+                    const f2 k = (splat2(1.0f) - t) * splat2(0.0f);  // (1 - t) * color_2, color_2 = 0
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+                        ca |= f32_to_u8(v.x) << (8 * ch);
+                        cb |= f32_to_u8(v.y) << (8 * ch);
+                    }
+                } else {
+                    float va[VARY_STRIDE], vb[VARY_STRIDE];
+                    va[0] = __uint_as_float(qa[3].z); va[1] = __uint_as_float(qa[3].w);
+                    vb[0] = __uint_as_float(qb[3].z); vb[1] = __uint_as_float(qb[3].w);
 #pragma unroll
                     for (int i = 4; i < P; i++) {
-                        v[4 * i - 14] = __uint_as_float(q[i].x);
-                        v[4 * i - 13] = __uint_as_float(q[i].y);
-                        v[4 * i - 12] = __uint_as_float(q[i].z);
-                        v[4 * i - 11] = __uint_as_float(q[i].w);
+                        va[4 * i - 14] = __uint_as_float(qa[i].x); va[4 * i - 13] = __uint_as_float(qa[i].y);
+                        va[4 * i - 12] = __uint_as_float(qa[i].z); va[4 * i - 11] = __uint_as_float(qa[i].w);
+                        vb[4 * i - 14] = __uint_as_float(qb[i].x); vb[4 * i - 13] = __uint_as_float(qb[i].y);
+                        vb[4 * i - 12] = __uint_as_float(qb[i].z); vb[4 * i - 11] = __uint_as_float(qb[i].w);
                     }
-                    c = fragment_stage<FS>(a.u, a.tex, v, bar, (uint32_t)px, (uint32_t)py[u], z, a.shadow,
-                                           (uint32_t)W, (uint32_t)H, e1);
+                    ca = fragment_color<FS>(a.u, a.tex, va, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, (uint32_t)px,
+                                            (uint32_t)py[0], z.x, a.shadow, (uint32_t)W, (uint32_t)H, ea);
+                    cb = fragment_color<FS>(a.u, a.tex, vb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, (uint32_t)px,
+                                            (uint32_t)py[1], z.y, a.shadow, (uint32_t)W, (uint32_t)H, eb);
                 }
-                if (won[u]) {
-                    zout[u] = z;
-                    rgb[u] = c;
-                    tri[u] = q[3].y;
-                    err |= e1;
-                }
+            }
+            uint32_t err = 0u;
+            if (won[0]) {
+                zout[0] = z.x;
+                rgb[0] = ca;
+                tri[0] = qa[3].y;
+                err |= ea;
+            }
+            if (won[1]) {
+                zout[1] = z.y;
+                rgb[1] = cb;
+                tri[1] = qb[3].y;
+                err |= eb;
             }
             if (err) atomicOr(a.err, err);
         }
 
 #pragma unroll
-        for (int u = 0; u < SHADE_G; u++) {
+        for (int u = 0; u < 2; u++) {
             if (!DEPTH && !a.fresh && live[u] && !won[u]) {
                 // untouched pixel of an accumulate render: its colour may share a dword with a
                 // touched neighbour, so fetch it
@@ -480,11 +551,9 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
         }
     }
 
-    // the bin is consumed: leave the counter at zero for the next pass / frame
-    __syncthreads();
-    if (tid == 0u) {
-        a.tile_count[tile] = 0u;
-        if (a.stamps) {
+    if (a.stamps) {
+        __syncthreads();
+        if (tid == 0u) {
             a.stamps[8u * tile + 0u] = t_start;
             a.stamps[8u * tile + 1u] = wall_clock64();
             a.stamps[8u * tile + 2u] = n;
@@ -573,7 +642,7 @@ int launch_tile(int fs, const TileArgs &a, hipStream_t st)
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
-    const dim3 grid(n_tiles), block(256);
+    const dim3 grid(2u * n_tiles), block(256);
     switch (fs) {
     case FS_DEFAULT: hipLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, a); break;
     case FS_PHONG: hipLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, a); break;

@@ -104,7 +104,16 @@ struct tr_scene {
     float *d_pos = nullptr, *d_tex = nullptr, *d_nrm = nullptr;
     uint32_t *d_idx = nullptr;
     uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
-    uint32_t *d_tile_count = nullptr;
+    // Per-tile polygon counters, busy-tile lists and their lengths, double buffered: a pass fills and
+    // reads set `cur`, its tile kernel zeroes the other set for the next pass of the same kind.
+    // Colour passes (the scene's band) and depth passes (always the whole frame) have different
+    // tile grids, hence a state each.
+    struct BinState {
+        uint32_t *count[2] = { nullptr, nullptr };
+        uint32_t *list[2] = { nullptr, nullptr };
+        uint32_t *nbusy = nullptr;  // two words
+        int cur = 0;
+    } bin_color, bin_depth;
     Piece *d_bins = nullptr;     // n_tiles_full x bin_cap records of rec_pieces x 16 B
     uint32_t bin_cap = 0;        // records per tile; grown on overflow
     uint32_t rec_pieces = 0;
@@ -356,7 +365,10 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.mesh = s->mesh;
     sa.frame = frame;
     sa.u = du;
-    sa.tile_count = s->d_tile_count;
+    tr_scene::BinState &bs = depth_pass ? s->bin_depth : s->bin_color;
+    sa.tile_count = bs.count[bs.cur];
+    sa.busy_list = bs.list[bs.cur];
+    sa.busy_n = bs.nbusy + bs.cur;
     sa.bins = s->d_bins;
     sa.bin_cap = s->bin_cap;
     sa.rec_pieces = s->rec_pieces;
@@ -372,7 +384,11 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.bins = s->d_bins;
     ta.bin_cap = s->bin_cap;
     ta.rec_pieces = s->rec_pieces;
-    ta.tile_count = s->d_tile_count;
+    ta.tile_count = bs.count[bs.cur];
+    ta.busy_list = bs.list[bs.cur];
+    ta.busy_n = bs.nbusy + bs.cur;
+    ta.tile_count_next = bs.count[bs.cur ^ 1];
+    ta.busy_n_next = bs.nbusy + (bs.cur ^ 1);
     ta.frame = frame;
     ta.u = du;
     ta.tex = s->tex;
@@ -392,6 +408,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
         int rc = launch_tile(p.fs, ta, s->stream);
         if (rc) return launch_status(rc, "k_tile");
     }
+    bs.cur ^= 1;
     return TR_OK;
 }
 
@@ -433,7 +450,13 @@ void destroy(tr_scene *s)
     dev_free(s->d_nrm);
     dev_free(s->d_idx);
     for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
-    dev_free(s->d_tile_count);
+    for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
+        for (int k = 0; k < 2; k++) {
+            dev_free(b->count[k]);
+            dev_free(b->list[k]);
+        }
+        dev_free(b->nbusy);
+    }
     dev_free(s->d_bins);
     dev_free(s->d_bin_need);
     dev_free(s->d_z);
@@ -542,7 +565,16 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     }
 
     // bins
-    if ((st = dev_alloc(&s->d_tile_count, (size_t)s->n_tiles_full))) return st;
+    for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
+        const size_t nt = (b == &s->bin_color) ? s->n_tiles : s->n_tiles_full;
+        for (int k = 0; k < 2; k++) {
+            if ((st = dev_alloc(&b->count[k], nt))) return st;
+            if ((st = dev_alloc(&b->list[k], nt))) return st;
+            HIP_TRY(hipMemset(b->count[k], 0, nt * 4));
+        }
+        if ((st = dev_alloc(&b->nbusy, 2))) return st;
+        HIP_TRY(hipMemset(b->nbusy, 0, 8));
+    }
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
     uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
     if (cap > mesh->n_tri) cap = mesh->n_tri;               // a bin never holds more than all polygons
@@ -550,7 +582,6 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->bin_cap = (uint32_t)cap;
     s->rec_pieces = (pipe == P_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     if ((st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
-    HIP_TRY(hipMemset(s->d_tile_count, 0, (size_t)s->n_tiles_full * 4));
     HIP_TRY(hipMemset(s->d_bin_need, 0, 4));
 
     // render targets; Buffer::new / Scene::new zero-fill them (shader.rs:46-47, scene.rs:71)

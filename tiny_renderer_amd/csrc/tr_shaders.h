@@ -8,6 +8,7 @@
 #pragma once
 
 #include "tr_math.h"
+#include "tr_pk.h"
 #include "tr_types.h"
 
 namespace tr {
@@ -217,6 +218,35 @@ TR_HD vec3 barycentric_by(float cx, float cy, Recip rz)
     return make3(1.0f - div_by(cx + cy, rz), div_by(cx, rz), div_by(cy, rz));
 }
 
+// RN(1 / cross.z) of a polygon record: computed once per polygon by the setup kernel, carried
+// in the record's spare word.
+TR_HD float record_recip(const RasterRec &r) { return 1.0f / edge_setup(r).cz; }
+
+// Two pixels at once (same polygon in coverage, possibly different ones in shading): the raw
+// cross products of scene.rs:178-187 per component.
+struct Edge2 {
+    f2 a0, a1, b0, b1, cz, y;
+};
+
+TR_HD void edge_cross2(const Edge2 &e, f2 a2, f2 b2, f2 &cx, f2 &cy)
+{
+    cx = e.a1 * b2 - a2 * e.b1;
+    cy = a2 * e.b0 - e.a0 * b2;
+}
+
+struct Bary2 {
+    f2 x, y, z;
+};
+
+TR_HD Bary2 barycentric2(f2 cx, f2 cy, const Edge2 &e)
+{
+    Bary2 b;
+    b.x = splat2(1.0f) - div_by2(cx + cy, e.cz, e.y);
+    b.y = div_by2(cx, e.cz, e.y);
+    b.z = div_by2(cy, e.cz, e.y);
+    return b;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fragment stage
 // ---------------------------------------------------------------------------------------------
@@ -277,17 +307,12 @@ TR_HD float shadow_fetch(const float *shadow, uint32_t W, uint32_t H, vec3 c, ui
 
 // Runs fragment closure `FS` for a fragment whose depth test has already passed.
 // Returns packed rgb (r | g<<8 | b<<16).
+// The part of fragment closure `FS` after `uv = vertex_uvs * bar`: texel fetches, lighting, blend.
 template <int FS>
-TR_HD uint32_t fragment_stage(const DevUniforms &u, const DevTextures &tex, const float *vary,
-                              vec3 bar, uint32_t x, uint32_t y, float z, const float *shadow,
-                              uint32_t W, uint32_t H, uint32_t &err)
+TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, const float *vary,
+                              vec3 bar, float uu, float vv, uint32_t x, uint32_t y, float z,
+                              const float *shadow, uint32_t W, uint32_t H, uint32_t &err)
 {
-    // uv = vertex_uvs * bar (2x3 gemv)
-    float uu = vary[0] * bar.x, vv = vary[1] * bar.x;
-    uu = vary[2] * bar.y + uu;
-    vv = vary[3] * bar.y + vv;
-    uu = vary[4] * bar.z + uu;
-    vv = vary[5] * bar.z + vv;
     vec3 tl = make3(u.t_light[0], u.t_light[1], u.t_light[2]);
 
     if (FS == FS_DEFAULT) {
@@ -391,6 +416,20 @@ TR_HD uint32_t fragment_stage(const DevUniforms &u, const DevTextures &tex, cons
         return pack_rgb(g, g, g);
     }
     return 0u;
+}
+
+template <int FS>
+TR_HD uint32_t fragment_stage(const DevUniforms &u, const DevTextures &tex, const float *vary,
+                              vec3 bar, uint32_t x, uint32_t y, float z, const float *shadow,
+                              uint32_t W, uint32_t H, uint32_t &err)
+{
+    // uv = vertex_uvs * bar (2x3 gemv)
+    float uu = vary[0] * bar.x, vv = vary[1] * bar.x;
+    uu = vary[2] * bar.y + uu;
+    vv = vary[3] * bar.y + vv;
+    uu = vary[4] * bar.z + uu;
+    vv = vary[5] * bar.z + vv;
+    return fragment_color<FS>(u, tex, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
 }
 
 }  // namespace tr

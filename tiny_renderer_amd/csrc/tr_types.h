@@ -45,7 +45,10 @@ enum FsKind : int {
 // 128-byte lines, 128 px of f32 depth = 512 B = four lines: every row a tile writes is made of
 // whole cache lines.
 constexpr int TILE_W = 128;
-constexpr int TILE_H = 16;
+#ifndef TR_TILE_H
+#define TR_TILE_H 16
+#endif
+constexpr int TILE_H = TR_TILE_H;
 constexpr int QUAD = 32;
 
 // Raster part of a polygon record (64 B).  Mirrors Buffer.vertex_t_raster / vertex_z_values
@@ -137,6 +140,8 @@ struct SetupArgs {
     DevFrame frame;
     DevUniforms u;
     uint32_t *tile_count;
+    uint32_t *busy_list;  // tiles that received their first record, in arrival order
+    uint32_t *busy_n;     // length of busy_list
     Piece *bins;        // n_tiles x bin_cap records of rec_pieces x 16 B
     uint32_t bin_cap;
     uint32_t rec_pieces;
@@ -148,7 +153,13 @@ struct TileArgs {
     const Piece *bins;
     uint32_t bin_cap;
     uint32_t rec_pieces;
-    uint32_t *tile_count;  // reset to 0 by the tile kernel for the next pass
+    // Counters ping-pong between passes of the same kind: this pass reads `tile_count` /
+    // `busy_list` / `busy_n` (filled by its k_setup) and zeroes the other set for the next pass.
+    const uint32_t *tile_count;
+    const uint32_t *busy_list;
+    const uint32_t *busy_n;
+    uint32_t *tile_count_next;
+    uint32_t *busy_n_next;
     DevFrame frame;
     DevUniforms u;
     DevTextures tex;

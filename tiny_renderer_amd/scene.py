@@ -133,7 +133,7 @@ class Scene:
 
     def debug_tile_stamps(self):
         """[n_tiles, 8] uint64: start, end (100 MHz ticks), polygons in the bin, hardware id, bin staged, coverage done."""
-        cap = ((self.width + 127) // 128) * ((self.height + 15) // 16)
+        cap = ((self.width + 127) // 128) * ((self.height + 7) // 8)
         out = np.zeros((cap, 8), np.uint64)
         n = check(load_library().tr_scene_debug_tile_stamps(self._h, out.ctypes.data, cap))
         return out[:n]
