@@ -226,7 +226,10 @@ def main():
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(workload)
+                    # HBM bytes of one k_tile launch from the rocprofv3 PMC passes of this workload
+                    # (FETCH_SIZE x2 + WRITE_SIZE, see profiles/pmc_traffic.json); null when this
+                    # workload has not been profiled
+                    traffic = json.load(open(tf)).get(workload, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
