@@ -94,8 +94,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # TR_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, band scene, in-place
+    # all-gather) with a single rank: a rehearsal of the RCCL plumbing on a one-GPU box.
+    use_dist = world > 1 or os.environ.get("TR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import tiny_renderer_amd as T
@@ -122,7 +128,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     fb = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
     band = None
-    if world > 1:
+    if use_dist:
         rows = [(r * H) // world for r in range(world + 1)]
         band = (rows[rank], rows[rank + 1])
         if len({rows[r + 1] - rows[r] for r in range(world)}) != 1:
@@ -130,7 +136,7 @@ def main():
     scene = T.Scene(W, H, mesh, texs, pipe, device=local_rank, stream=stream,
                     frame_buffer_device=fb.data_ptr(), band_rows=band)
     chunk = None
-    if world > 1:
+    if use_dist:
         n = (band[1] - band[0]) * W * 3
         chunk = fb[rank * n:(rank + 1) * n]
 
@@ -139,11 +145,11 @@ def main():
         scene.set_light_direction(lt)
         scene.set_camera(*cam)
         scene.render()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(fb, chunk)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -159,7 +165,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     status = scene.sync()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -249,7 +255,7 @@ def main():
             "data": data,
             "config": {"workload": workload, "n_shaded_per_frame": n_shaded,
                        "polygons": int(mesh["idx"].shape[0]),
-                       "sharding": "screen row bands + RCCL all-gather of the framebuffer" if world > 1 else "none"},
+                       "sharding": "screen row bands + RCCL all-gather of the framebuffer" if use_dist else "none"},
             "frames_per_s": round(args.steps / elapsed, 1),
             "framebuffer_mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
             "parity_vs_oracle": {"ok": parity_ok, "max_abs_rgb_diff": int(diff.max()), "tolerance": tol},
@@ -260,7 +266,7 @@ def main():
         }
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     scene.close()
