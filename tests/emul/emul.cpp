@@ -99,7 +99,10 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
         tx.w[k] = tex[k].w;
         tx.h[k] = tex[k].h;
     }
-    DevMesh dm = { mesh->pos, mesh->tex, mesh->nrm, mesh->idx, mesh->n_tri };
+    std::vector<float> rows((size_t)mesh->n_tri * TRI_FLOATS);
+    for (uint32_t t = 0; t < mesh->n_tri; t++)
+        gather_polygon(mesh->pos, mesh->tex, mesh->nrm, mesh->idx + 9u * (size_t)t, &rows[(size_t)t * TRI_FLOATS]);
+    DevMesh dm = { rows.data(), mesh->n_tri };
     if (band_row0 == 0 && band_row1 == 0) band_row1 = H;
 
     tr_uniforms un;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
 
     // Binning.  One lane per polygon would serialise a polygon's atomics (a polygon spanning 30
     // tiles = 30 dependent round trips); instead the wave's (polygon, tile) pairs are numbered by
-    // a prefix sum and dealt round-robin to the lanes, four per lane per trip so that the four
+    // a prefix sum and dealt round-robin to the lanes, PAIRS per lane per trip so that their
     // returning atomics are in flight together.
     int32_t incl = cnt;
 #pragma unroll
@@ -103,11 +103,12 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
     s_ntx[lane] = ntx;
     __syncthreads();
 
-    for (int32_t p0 = (int32_t)lane; p0 < total; p0 += 256) {
-        int32_t own[4], tile[4];
-        uint32_t slot[4];
+    constexpr int PAIRS = 8;  // pairs per lane per trip: their atomics are in flight together
+    for (int32_t p0 = (int32_t)lane; p0 < total; p0 += 64 * PAIRS) {
+        int32_t own[PAIRS], tile[PAIRS];
+        uint32_t slot[PAIRS], pos[PAIRS];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PAIRS; k++) {
             const int32_t p = p0 + 64 * k;
             own[k] = -1;
             tile[k] = 0;
@@ -129,13 +130,31 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < PAIRS; k++)
             slot[k] = own[k] >= 0 ? atomicAdd(&a.tile_count[tile[k]], 1u) : 0u;
+
+        // First record of a tile: put the tile on the busy list, which k_tile runs first.  Every
+        // lane of every wave shares ONE list counter (a single word takes ~90 atomics per
+        // microsecond), so the wave reserves a range with one atomic per trip and its lanes take
+        // consecutive entries.
+        uint32_t firsts = 0u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PAIRS; k++) {
+            const unsigned long long mask = __ballot(own[k] >= 0 && slot[k] == 0u);
+            pos[k] = firsts + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            firsts += (uint32_t)__builtin_popcountll(mask);
+        }
+        if (firsts) {
+            uint32_t base = 0u;
+            if (lane == 0u) base = atomicAdd(a.busy_n, firsts);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+#pragma unroll
+            for (int k = 0; k < PAIRS; k++)
+                if (own[k] >= 0 && slot[k] == 0u) a.busy_list[base + pos[k]] = (uint32_t)tile[k];
+        }
+#pragma unroll
+        for (int k = 0; k < PAIRS; k++) {
             if (own[k] < 0) continue;
-            // first record of this tile: put the tile on the busy list, which k_tile runs first
-            if (slot[k] == 0u) a.busy_list[atomicAdd(a.busy_n, 1u)] = (uint32_t)tile[k];
             if (slot[k] < a.bin_cap) {
                 uint4 *dst = reinterpret_cast<uint4 *>(a.bins) + ((size_t)tile[k] * a.bin_cap + slot[k]) * P;
                 const uint4 *src = s_rec + own[k] * P;
@@ -329,6 +348,20 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 r3 = s_rec[jj * P + 3];
                 ry = s_rec[jj * P + (P - 1)].w;
             }
+            // The polygon's part of to_barycentric_coord (scene.rs:178-187), for the 64 records
+            // of this round at once (lane l = record l).  Orientation is normalised so that
+            // cross.z > 0: negating a0, a1, b0, b1 flips the sign of cross.x and cross.y exactly,
+            // and dividing them by -cross.z (reciprocal -y) gives bit-identical quotients, so one
+            // branch-free form of the inside test serves both windings.
+            float la0 = (float)isub((int32_t)r1.z, (int32_t)r1.x), la1 = (float)isub((int32_t)r2.x, (int32_t)r1.x);
+            float lb0 = (float)isub((int32_t)r1.w, (int32_t)r1.y), lb1 = (float)isub((int32_t)r2.y, (int32_t)r1.y);
+            float lcz = la0 * lb1 - la1 * lb0;
+            float lry = __uint_as_float(ry);
+            if (lcz < 0.0f) {
+                la0 = -la0; la1 = -la1; lb0 = -lb0; lb1 = -lb1;
+                lcz = -lcz;
+                lry = -lry;
+            }
             const bool touch = imax((int32_t)r0.x, qx0) <= imin((int32_t)r0.y, qx0 + QUAD - 1) &&
                                imax((int32_t)r0.z, qy0) <= imin((int32_t)r0.w, qy0 + TILE_H - 1);
             unsigned long long todo = __ballot(touch);
@@ -337,42 +370,47 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 todo &= todo - 1ull;
                 const int32_t bx0 = imax(bcast(r0.x, l), qx0), bx1 = imin(bcast(r0.y, l), qx0 + QUAD - 1);
                 const int32_t by0 = imax(bcast(r0.z, l), qy0), by1 = imin(bcast(r0.w, l), qy0 + TILE_H - 1);
-                const int32_t x0 = bcast(r1.x, l), y0 = bcast(r1.y, l), x1 = bcast(r1.z, l), y1 = bcast(r1.w, l);
-                const int32_t x2 = bcast(r2.x, l), y2 = bcast(r2.y, l);
+                const int32_t x0 = bcast(r1.x, l), y0 = bcast(r1.y, l);
                 const float z0 = __int_as_float(bcast(r2.z, l)), z1 = __int_as_float(bcast(r2.w, l));
                 const float z2 = __int_as_float(bcast(r3.x, l));
                 const uint32_t id = (uint32_t)bcast(r3.y, l);
                 const uint32_t slot1 = c0 + j0 + l + 1u;
-                // the polygon's part of to_barycentric_coord (scene.rs:178-187), for both rows
                 Edge2 e;
-                e.a0 = splat2((float)isub(x1, x0));
-                e.a1 = splat2((float)isub(x2, x0));
-                e.b0 = splat2((float)isub(y1, y0));
-                e.b1 = splat2((float)isub(y2, y0));
-                e.cz = e.a0 * e.b1 - e.a1 * e.b0;
-                e.y = splat2(__int_as_float(bcast(ry, l)));
-                const float cz = e.cz.x;
+                e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
+                e.a1 = splat2(__int_as_float(bcast(__float_as_uint(la1), l)));
+                e.b0 = splat2(__int_as_float(bcast(__float_as_uint(lb0), l)));
+                e.b1 = splat2(__int_as_float(bcast(__float_as_uint(lb1), l)));
+                const float cz = __int_as_float(bcast(__float_as_uint(lcz), l));
+                e.cz = splat2(cz);
+                e.y = splat2(__int_as_float(bcast(__float_as_uint(lry), l)));
                 // this lane's two pixels: (px, pya) in block row 0 and (px, pyb) in block row 1
                 const int32_t pya = qy0 + ly, pyb = qy0 + 8 + ly;
                 const f2 b2 = mk2((float)isub(y0, pya), (float)isub(y0, pyb));
                 const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
                 const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
                 for (int32_t ib = ib0; ib <= ib1; ib++) {
+                    // the two pixels' current keys, requested before the arithmetic that decides
+                    // whether they are needed (LDS latency hidden inside the wave)
+                    uint2 *slot_a = wkey + ((ib << 6) + (int32_t)lane), *slot_b = slot_a + (NBX << 6);
+                    const uint2 cur_a = *slot_a, cur_b = *slot_b;
                     const int32_t px = qx0 + ib * 8 + lx;
                     const bool inx = px >= bx0 && px <= bx1;
                     f2 cx, cy;
                     edge_cross2(e, splat2((float)isub(x0, px)), b2, cx, cy);
-                    const bool hita = inx && rowa && covers(cx.x, cy.x, cz);
-                    const bool hitb = inx && rowb && covers(cx.y, cy.y, cz);
+                    const f2 sum = cx + cy;
+                    const bool hita = inx && rowa && cx.x >= 0.0f && cy.x >= 0.0f && sum.x <= cz;
+                    const bool hitb = inx && rowb && cx.y >= 0.0f && cy.y >= 0.0f && sum.y <= cz;
                     if (hita || hitb) {
-                        const Bary2 bar = barycentric2(cx, cy, e);
+                        // depth of both fragments; only compared here (the survivor's stored z is
+                        // recomputed with exact zero signs when it is shaded)
+                        const Bary2 bar = barycentric2_for_compare(cx, cy, e);
                         const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
                             if (!(h == 0 ? hita : hitb)) continue;
                             const float zf = h == 0 ? z.x : z.y;
-                            uint2 *slot = wkey + (((h * NBX + ib) << 6) + (int32_t)lane);
-                            const uint2 cur = *slot;
+                            uint2 *slot = h == 0 ? slot_a : slot_b;
+                            const uint2 cur = h == 0 ? cur_a : cur_b;
                             const float zc = __uint_as_float(cur.x);
                             bool win = zf > zc;
                             if (zf == zc) {
@@ -409,145 +447,183 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
     const int32_t px = qx0 + hx;
-#pragma unroll 1
-    for (int32_t sstep = 0; sstep < TILE_H / 4; sstep++) {
+    constexpr int NSTEP = TILE_H / 4;
+    // For the plain texture pipelines (default, phong) the NSTEP steps run as two passes: first
+    // every step's record gathers, barycentrics and texel fetches are issued, then every step is
+    // blended and stored, so the texel latency is exposed once per wave instead of once per
+    // step.  The heavier closures keep one pass per step (their registers would not fit).
+    constexpr bool TWO_PASS = (FS == FS_DEFAULT || FS == FS_PHONG);
+
+    struct StepState {
         int32_t py[2];
         bool live[2], won[2];
-        uint32_t wslot[2], tri[2], rgb[2];
+        uint32_t tri[2], rgb[2], texel[2];
         float zout[2];
+        f2 t;
+    };
+
+    // Pass 1 of a step: survivors, their records, barycentrics, depth, uv, colour (or, for the
+    // two-pass pipelines, the texel fetch and the diffuse coefficient).
+    auto shade_front = [&](int32_t sstep, StepState &st) {
+        uint32_t wslot[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int32_t qy = sstep * 4 + u * 2 + hrow;
-            py[u] = qy0 + qy;
-            live[u] = px < W && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+            st.py[u] = qy0 + qy;
+            st.live[u] = px < W && st.py[u] >= a.frame.band_y0 && st.py[u] < a.frame.band_y1;
             const uint32_t s1 = wkey[key_slot((uint32_t)hx, (uint32_t)qy)].y;
-            won[u] = live[u] && s1 != 0u;
-            wslot[u] = won[u] ? s1 - 1u : 0u;
-            tri[u] = NO_WINNER;
-            rgb[u] = 0u;
-            zout[u] = bits_f32(TR_F32_MIN_BITS);
+            st.won[u] = st.live[u] && s1 != 0u;
+            wslot[u] = st.won[u] ? s1 - 1u : 0u;
+            st.tri[u] = NO_WINNER;
+            st.rgb[u] = 0u;
+            st.texel[u] = 0u;
+            st.zout[u] = bits_f32(TR_F32_MIN_BITS);
         }
-        if (__any(won[0] || won[1])) {
-            uint4 qa[P], qb[P];
-            if (resident) {
+        st.t = splat2(0.0f);
+        if (!__any(st.won[0] || st.won[1])) return;
+        uint4 qa[P], qb[P];
+        if (resident) {
 #pragma unroll
-                for (int i = 1; i < P; i++) {
-                    qa[i] = s_rec[wslot[0] * P + i];
-                    qb[i] = s_rec[wslot[1] * P + i];
-                }
+            for (int i = 1; i < P; i++) {
+                qa[i] = s_rec[wslot[0] * P + i];
+                qb[i] = s_rec[wslot[1] * P + i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 1; i < P; i++) {
+                qa[i] = bin[(size_t)wslot[0] * P + i];
+                qb[i] = bin[(size_t)wslot[1] * P + i];
+            }
+        }
+        // to_barycentric_coord for both pixels (each against its own polygon)
+        Edge2 e;
+        e.a0 = mk2((float)isub((int32_t)qa[1].z, (int32_t)qa[1].x), (float)isub((int32_t)qb[1].z, (int32_t)qb[1].x));
+        e.a1 = mk2((float)isub((int32_t)qa[2].x, (int32_t)qa[1].x), (float)isub((int32_t)qb[2].x, (int32_t)qb[1].x));
+        e.b0 = mk2((float)isub((int32_t)qa[1].w, (int32_t)qa[1].y), (float)isub((int32_t)qb[1].w, (int32_t)qb[1].y));
+        e.b1 = mk2((float)isub((int32_t)qa[2].y, (int32_t)qa[1].y), (float)isub((int32_t)qb[2].y, (int32_t)qb[1].y));
+        e.cz = e.a0 * e.b1 - e.a1 * e.b0;
+        e.y = mk2(__uint_as_float(qa[P - 1].w), __uint_as_float(qb[P - 1].w));
+        const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));
+        const f2 b2 = mk2((float)isub((int32_t)qa[1].y, st.py[0]), (float)isub((int32_t)qb[1].y, st.py[1]));
+        f2 cx, cy;
+        edge_cross2(e, a2, b2, cx, cy);
+        const Bary2 bar = barycentric2(cx, cy, e);
+        const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
+                            mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
+                            mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
+        uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
+        if (!DEPTH) {
+            // uv = vertex_uvs * bar (2x3 gemv), both pixels
+            f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
+            f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
+            uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
+            vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
+            uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
+            vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
+            if (TWO_PASS) {
+                // shader.rs:318-333 / 386-401: texel now, color_blend in the second pass
+                st.texel[0] = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
+                st.texel[1] = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
+                const f2 i0 = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
+                st.t = i0;
+                if (FS == FS_PHONG)
+                    st.t = dot3_2(bar.x, bar.y, bar.z, i0, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
+                                  mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
             } else {
+                float va[VARY_STRIDE], vb[VARY_STRIDE];
+                va[0] = __uint_as_float(qa[3].z); va[1] = __uint_as_float(qa[3].w);
+                vb[0] = __uint_as_float(qb[3].z); vb[1] = __uint_as_float(qb[3].w);
 #pragma unroll
-                for (int i = 1; i < P; i++) {
-                    qa[i] = bin[(size_t)wslot[0] * P + i];
-                    qb[i] = bin[(size_t)wslot[1] * P + i];
+                for (int i = 4; i < P; i++) {
+                    va[4 * i - 14] = __uint_as_float(qa[i].x); va[4 * i - 13] = __uint_as_float(qa[i].y);
+                    va[4 * i - 12] = __uint_as_float(qa[i].z); va[4 * i - 11] = __uint_as_float(qa[i].w);
+                    vb[4 * i - 14] = __uint_as_float(qb[i].x); vb[4 * i - 13] = __uint_as_float(qb[i].y);
+                    vb[4 * i - 12] = __uint_as_float(qb[i].z); vb[4 * i - 11] = __uint_as_float(qb[i].w);
                 }
+                ca = fragment_color<FS>(a.u, a.tex, va, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, (uint32_t)px,
+                                        (uint32_t)st.py[0], z.x, a.shadow, (uint32_t)W, (uint32_t)H, ea);
+                cb = fragment_color<FS>(a.u, a.tex, vb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, (uint32_t)px,
+                                        (uint32_t)st.py[1], z.y, a.shadow, (uint32_t)W, (uint32_t)H, eb);
             }
-            // to_barycentric_coord for both pixels (each against its own polygon)
-            Edge2 e;
-            e.a0 = mk2((float)isub((int32_t)qa[1].z, (int32_t)qa[1].x), (float)isub((int32_t)qb[1].z, (int32_t)qb[1].x));
-            e.a1 = mk2((float)isub((int32_t)qa[2].x, (int32_t)qa[1].x), (float)isub((int32_t)qb[2].x, (int32_t)qb[1].x));
-            e.b0 = mk2((float)isub((int32_t)qa[1].w, (int32_t)qa[1].y), (float)isub((int32_t)qb[1].w, (int32_t)qb[1].y));
-            e.b1 = mk2((float)isub((int32_t)qa[2].y, (int32_t)qa[1].y), (float)isub((int32_t)qb[2].y, (int32_t)qb[1].y));
-            e.cz = e.a0 * e.b1 - e.a1 * e.b0;
-            e.y = mk2(__uint_as_float(qa[P - 1].w), __uint_as_float(qb[P - 1].w));
-            const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));
-            const f2 b2 = mk2((float)isub((int32_t)qa[1].y, py[0]), (float)isub((int32_t)qb[1].y, py[1]));
-            f2 cx, cy;
-            edge_cross2(e, a2, b2, cx, cy);
-            const Bary2 bar = barycentric2(cx, cy, e);
-            const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
-                                mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
-                                mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
-            uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
-            if (!DEPTH) {
-                // uv = vertex_uvs * bar (2x3 gemv), both pixels
-                f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
-                f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
-                uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
-                vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
-                uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
-                vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
-                if (FS == FS_DEFAULT || FS == FS_PHONG) {
-                    // shader.rs:318-333 / 386-401: texel, diffuse coefficient, color_blend
-                    const uint32_t ta = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
-                    const uint32_t tb = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
-                    const f2 i0 = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
-                    f2 t = i0;
-                    if (FS == FS_PHONG)
-                        t = dot3_2(bar.x, bar.y, bar.z, i0, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
-                                   mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
-                    const f2 k = (splat2(1.0f) - t) * splat2(0.0f);  // (1 - t) * color_2, color_2 = 0
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
-                        ca |= f32_to_u8(v.x) << (8 * ch);
-                        cb |= f32_to_u8(v.y) << (8 * ch);
-                    }
-                } else {
-                    float va[VARY_STRIDE], vb[VARY_STRIDE];
-                    va[0] = __uint_as_float(qa[3].z); va[1] = __uint_as_float(qa[3].w);
-                    vb[0] = __uint_as_float(qb[3].z); vb[1] = __uint_as_float(qb[3].w);
-#pragma unroll
-                    for (int i = 4; i < P; i++) {
-                        va[4 * i - 14] = __uint_as_float(qa[i].x); va[4 * i - 13] = __uint_as_float(qa[i].y);
-                        va[4 * i - 12] = __uint_as_float(qa[i].z); va[4 * i - 11] = __uint_as_float(qa[i].w);
-                        vb[4 * i - 14] = __uint_as_float(qb[i].x); vb[4 * i - 13] = __uint_as_float(qb[i].y);
-                        vb[4 * i - 12] = __uint_as_float(qb[i].z); vb[4 * i - 11] = __uint_as_float(qb[i].w);
-                    }
-                    ca = fragment_color<FS>(a.u, a.tex, va, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, (uint32_t)px,
-                                            (uint32_t)py[0], z.x, a.shadow, (uint32_t)W, (uint32_t)H, ea);
-                    cb = fragment_color<FS>(a.u, a.tex, vb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, (uint32_t)px,
-                                            (uint32_t)py[1], z.y, a.shadow, (uint32_t)W, (uint32_t)H, eb);
-                }
-            }
-            uint32_t err = 0u;
-            if (won[0]) {
-                zout[0] = z.x;
-                rgb[0] = ca;
-                tri[0] = qa[3].y;
-                err |= ea;
-            }
-            if (won[1]) {
-                zout[1] = z.y;
-                rgb[1] = cb;
-                tri[1] = qb[3].y;
-                err |= eb;
-            }
-            if (err) atomicOr(a.err, err);
         }
+        uint32_t err = 0u;
+        if (st.won[0]) {
+            st.zout[0] = z.x;
+            st.rgb[0] = ca;
+            st.tri[0] = qa[3].y;
+            err |= ea;
+        }
+        if (st.won[1]) {
+            st.zout[1] = z.y;
+            st.rgb[1] = cb;
+            st.tri[1] = qb[3].y;
+            err |= eb;
+        }
+        if (err) atomicOr(a.err, err);
+    };
 
+    // Pass 2 of a step: color_blend for the two-pass pipelines, then the stores.
+    auto shade_back = [&](StepState &st) {
+        if (TWO_PASS) {
+            const f2 k = (splat2(1.0f) - st.t) * splat2(0.0f);  // (1 - t) * color_2, color_2 = 0
+            uint32_t ca = 0u, cb = 0u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const f2 v = st.t * mk2((float)((st.texel[0] >> (8 * ch)) & 0xFFu),
+                                        (float)((st.texel[1] >> (8 * ch)) & 0xFFu)) + k;
+                ca |= f32_to_u8(v.x) << (8 * ch);
+                cb |= f32_to_u8(v.y) << (8 * ch);
+            }
+            if (st.won[0]) st.rgb[0] = ca;
+            if (st.won[1]) st.rgb[1] = cb;
+        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            if (!DEPTH && !a.fresh && live[u] && !won[u]) {
+            if (!DEPTH && !a.fresh && st.live[u] && !st.won[u]) {
                 // untouched pixel of an accumulate render: its colour may share a dword with a
                 // touched neighbour, so fetch it
-                const uint8_t *old = a.fb + ((size_t)(H - 1 - py[u]) * W + px) * 3;
-                rgb[u] = pack_rgb(old[0], old[1], old[2]);
+                const uint8_t *old = a.fb + ((size_t)(H - 1 - st.py[u]) * W + px) * 3;
+                st.rgb[u] = pack_rgb(old[0], old[1], old[2]);
             }
             // depth: only pixels that changed (or every live pixel of a fresh tile)
-            const bool put = live[u] && (won[u] || a.fresh);
-            if (put) depth[(size_t)py[u] * W + px] = zout[u];
+            const bool put = st.live[u] && (st.won[u] || a.fresh);
+            if (put) depth[(size_t)st.py[u] * W + px] = st.zout[u];
             if (!DEPTH) {
-                if (a.winner && put) a.winner[(size_t)py[u] * W + px] = tri[u];
-                uint8_t *row = a.fb + ((size_t)(H - 1 - py[u]) * W + qx0) * 3;
+                if (a.winner && put) a.winner[(size_t)st.py[u] * W + px] = st.tri[u];
+                uint8_t *row = a.fb + ((size_t)(H - 1 - st.py[u]) * W + qx0) * 3;
                 if (a.aligned4) {
                     // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
                     // on, topped up from pixel p0+1
                     const uint32_t j = (uint32_t)hx;
                     const uint32_t p0 = (4u * j) / 3u, o = (4u * j) % 3u;
-                    const uint32_t c0 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + (p0 & 31u)), 64);
-                    const uint32_t c1 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + ((p0 + 1u) & 31u)), 64);
+                    const uint32_t c0 = (uint32_t)__shfl((int)st.rgb[u], (int)(half_base + (p0 & 31u)), 64);
+                    const uint32_t c1 = (uint32_t)__shfl((int)st.rgb[u], (int)(half_base + ((p0 + 1u) & 31u)), 64);
                     const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
-                    const bool row_live = py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+                    const bool row_live = st.py[u] >= a.frame.band_y0 && st.py[u] < a.frame.band_y1;
                     if (j < 24u && row_live && (qx0 * 3 + (int32_t)(4u * j)) < W * 3)
                         *reinterpret_cast<uint32_t *>(row + 4u * j) = dw;
                 } else if (put) {
                     uint8_t *p = row + 3 * hx;
-                    p[0] = (uint8_t)(rgb[u] & 0xFFu);
-                    p[1] = (uint8_t)((rgb[u] >> 8) & 0xFFu);
-                    p[2] = (uint8_t)((rgb[u] >> 16) & 0xFFu);
+                    p[0] = (uint8_t)(st.rgb[u] & 0xFFu);
+                    p[1] = (uint8_t)((st.rgb[u] >> 8) & 0xFFu);
+                    p[2] = (uint8_t)((st.rgb[u] >> 16) & 0xFFu);
                 }
             }
+        }
+    };
+
+    if (TWO_PASS) {
+        StepState st[NSTEP];
+#pragma unroll
+        for (int sstep = 0; sstep < NSTEP; sstep++) shade_front(sstep, st[sstep]);
+#pragma unroll
+        for (int sstep = 0; sstep < NSTEP; sstep++) shade_back(st[sstep]);
+    } else {
+#pragma unroll 1
+        for (int32_t sstep = 0; sstep < NSTEP; sstep++) {
+            StepState st;
+            shade_front(sstep, st);
+            shade_back(st);
         }
     }
 

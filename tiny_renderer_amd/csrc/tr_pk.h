@@ -53,6 +53,18 @@ TR_HD f2 div_by2(f2 x, f2 d, f2 y)
     return mk2(x.x == 0.0f ? q0.x : q.x, x.y == 0.0f ? q0.y : q.y);
 }
 
+// The same without the signed-zero repair: a quotient of a -0 numerator may come out as +0.
+// For consumers that only compare the result (or sums built from it) with IEEE ordering, where
+// +0 and -0 are the same value -- the coverage loop's depth test.
+TR_HD f2 div_by2_unsigned_zero(f2 x, f2 d, f2 y)
+{
+    const f2 q0 = x * y;
+    f2 e = fma2(-q0, d, x);
+    f2 q = fma2(e, y, q0);
+    e = fma2(-q, d, x);
+    return fma2(e, y, q);
+}
+
 // (a.x*b.x + a.y*b.y) + a.z*b.z per component, the dot3 order
 TR_HD f2 dot3_2(f2 ax, f2 ay, f2 az, f2 bx, f2 by, f2 bz) { return (ax * bx + ay * by) + az * bz; }
 

@@ -101,8 +101,7 @@ struct tr_scene {
     uint32_t n_tiles = 0, n_tiles_full = 0;
 
     // device allocations
-    float *d_pos = nullptr, *d_tex = nullptr, *d_nrm = nullptr;
-    uint32_t *d_idx = nullptr;
+    float *d_tri = nullptr;
     uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
     // Per-tile polygon counters, busy-tile lists and their lengths, double buffered: a pass fills and
     // reads set `cur`, its tile kernel zeroes the other set for the next pass of the same kind.
@@ -445,10 +444,7 @@ void destroy(tr_scene *s)
         (void)hipEventDestroy(ep.b);
     }
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
-    dev_free(s->d_pos);
-    dev_free(s->d_tex);
-    dev_free(s->d_nrm);
-    dev_free(s->d_idx);
+    dev_free(s->d_tri);
     for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
         for (int k = 0; k < 2; k++) {
@@ -535,19 +531,15 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
 
     const size_t npx = (size_t)width * height;
     int st;
-    // model
-    if ((st = dev_alloc(&s->d_pos, (size_t)mesh->n_pos * 3))) return st;
-    if ((st = dev_alloc(&s->d_tex, (size_t)mesh->n_tex * 3))) return st;
-    if ((st = dev_alloc(&s->d_nrm, (size_t)mesh->n_nrm * 3))) return st;
-    if ((st = dev_alloc(&s->d_idx, (size_t)mesh->n_tri * 9))) return st;
-    HIP_TRY(hipMemcpy(s->d_pos, mesh->pos, (size_t)mesh->n_pos * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_tex, mesh->tex, (size_t)mesh->n_tex * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_nrm, mesh->nrm, (size_t)mesh->n_nrm * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_idx, mesh->idx, (size_t)mesh->n_tri * 36, hipMemcpyHostToDevice));
-    s->mesh.pos = s->d_pos;
-    s->mesh.tex = s->d_tex;
-    s->mesh.nrm = s->d_nrm;
-    s->mesh.idx = s->d_idx;
+    // model: one flat row per polygon
+    {
+        std::vector<float> rows((size_t)mesh->n_tri * TRI_FLOATS);
+        for (uint32_t t = 0; t < mesh->n_tri; t++)
+            gather_polygon(mesh->pos, mesh->tex, mesh->nrm, mesh->idx + 9u * (size_t)t, &rows[(size_t)t * TRI_FLOATS]);
+        if ((st = dev_alloc(&s->d_tri, rows.size()))) return st;
+        HIP_TRY(hipMemcpy(s->d_tri, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    }
+    s->mesh.tri = s->d_tri;
     s->mesh.n_tri = mesh->n_tri;
 
     // textures: rgb8 -> rgba8 so a texel is one aligned dword fetch

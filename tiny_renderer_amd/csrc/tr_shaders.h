@@ -53,10 +53,26 @@ template <int VS>
 TR_HD bool vertex_stage(const DevMesh &mesh, const DevUniforms &u, uint32_t t, RasterRec &r,
                         float *vary, uint32_t &err)
 {
-    const uint32_t *ix = mesh.idx + 9u * (size_t)t;
-    vec3 p0 = load3(mesh.pos, ix[0]);
-    vec3 p1 = load3(mesh.pos, ix[3]);
-    vec3 p2 = load3(mesh.pos, ix[6]);
+    const float *row = mesh.tri + (size_t)TRI_FLOATS * t;
+    float m[TRI_FLOATS];
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+        for (int i = 0; i < TRI_FLOATS / 4; i++) {
+            const float4 q = r4[i];
+            m[4 * i] = q.x;
+            m[4 * i + 1] = q.y;
+            m[4 * i + 2] = q.z;
+            m[4 * i + 3] = q.w;
+        }
+    }
+#else
+    for (int i = 0; i < TRI_FLOATS; i++) m[i] = row[i];
+#endif
+    vec3 p0 = make3(m[0], m[1], m[2]);
+    vec3 p1 = make3(m[3], m[4], m[5]);
+    vec3 p2 = make3(m[6], m[7], m[8]);
 
     if (VS != VS_DEPTH) {
         if (cull_face(p0, p1, p2, u.camera_direction)) return false;
@@ -73,7 +89,7 @@ TR_HD bool vertex_stage(const DevMesh &mesh, const DevUniforms &u, uint32_t t, R
     } else if (VS == VS_PHONG) {
         // shader.rs:362-373
         for (int i = 0; i < 3; i++) {
-            vec3 n = load3(mesh.nrm, ix[3 * i + 2]);
+            vec3 n = make3(m[9 + 3 * i], m[10 + 3 * i], m[11 + 3 * i]);
             vary[6 + i] = dot3(tl, transform_normal(u.it_m, n));
         }
     } else if (VS == VS_DARBOUX) {
@@ -98,7 +114,7 @@ TR_HD bool vertex_stage(const DevMesh &mesh, const DevUniforms &u, uint32_t t, R
         vary[10] = r1.y;
         vary[11] = r1.z;
         for (int i = 0; i < 3; i++) {
-            vec3 tn = transform_normal(u.it_m, load3(mesh.nrm, ix[3 * i + 2]));
+            vec3 tn = transform_normal(u.it_m, make3(m[9 + 3 * i], m[10 + 3 * i], m[11 + 3 * i]));
             vary[12 + 3 * i + 0] = tn.x;
             vary[12 + 3 * i + 1] = tn.y;
             vary[12 + 3 * i + 2] = tn.z;
@@ -116,9 +132,8 @@ TR_HD bool vertex_stage(const DevMesh &mesh, const DevUniforms &u, uint32_t t, R
 
     // store_vertex_uvs, shader.rs:136-147: (u, 1 - v)
     for (int i = 0; i < 3; i++) {
-        uint32_t k = ix[3 * i + 1];
-        vary[2 * i + 0] = mesh.tex[3 * k];
-        vary[2 * i + 1] = 1.0f - mesh.tex[3 * k + 1];
+        vary[2 * i + 0] = m[18 + 2 * i];
+        vary[2 * i + 1] = 1.0f - m[19 + 2 * i];
     }
     return true;
 }
@@ -237,6 +252,17 @@ TR_HD void edge_cross2(const Edge2 &e, f2 a2, f2 b2, f2 &cx, f2 &cy)
 struct Bary2 {
     f2 x, y, z;
 };
+
+// Barycentrics whose zeros may carry the wrong sign (see div_by2_unsigned_zero): good for the
+// depth comparison of the coverage loop, not for values that are stored.
+TR_HD Bary2 barycentric2_for_compare(f2 cx, f2 cy, const Edge2 &e)
+{
+    Bary2 b;
+    b.x = splat2(1.0f) - div_by2_unsigned_zero(cx + cy, e.cz, e.y);
+    b.y = div_by2_unsigned_zero(cx, e.cz, e.y);
+    b.z = div_by2_unsigned_zero(cy, e.cz, e.y);
+    return b;
+}
 
 TR_HD Bary2 barycentric2(f2 cx, f2 cy, const Edge2 &e)
 {

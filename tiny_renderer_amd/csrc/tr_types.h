@@ -106,13 +106,28 @@ struct DevTextures {
     uint32_t w[4], h[4];
 };
 
+// The model as the vertex stage reads it: one 96-byte row per polygon, gathered from
+// obj::raw::RawObj's indexed arrays once at scene creation (the mesh never changes), so that the
+// per-frame vertex stage is a single coalesced sweep instead of index -> attribute chains:
+//   [0..8] positions p0 p1 p2 | [9..17] normals n0 n1 n2 | [18..23] tex coords u0 v0 u1 v1 u2 v2
+constexpr int TRI_FLOATS = 24;
 struct DevMesh {
-    const float *pos;
-    const float *tex;
-    const float *nrm;
-    const uint32_t *idx;
+    const float *tri;  // n_tri * TRI_FLOATS
     uint32_t n_tri;
 };
+
+// Fills one row of DevMesh::tri from the indexed arrays (util.rs:25-31, shader.rs:136-147,363-367).
+inline void gather_polygon(const float *pos, const float *tex, const float *nrm, const uint32_t *ix, float *out)
+{
+    for (int i = 0; i < 3; i++) {
+        for (int k = 0; k < 3; k++) {
+            out[3 * i + k] = pos[3 * ix[3 * i + 0] + k];
+            out[9 + 3 * i + k] = nrm[3 * ix[3 * i + 2] + k];
+        }
+        out[18 + 2 * i + 0] = tex[3 * ix[3 * i + 1] + 0];
+        out[18 + 2 * i + 1] = tex[3 * ix[3 * i + 1] + 1];
+    }
+}
 
 // Geometry of the rendered region.
 struct DevFrame {
