@@ -241,3 +241,14 @@ def test_device_math_selftest(built):
         host = (x / d).astype(np.float32)
     assert np.array_equal(dref[fin].view(np.uint32), host[fin].view(np.uint32))   # device '/' is IEEE
     assert np.array_equal(dv[fin].view(np.uint32), host[fin].view(np.uint32))     # shared reciprocal too
+
+
+@pytest.mark.parametrize("pipe", ["phong", "occlusion"])
+def test_every_tile_heavy(synthetic, pipe):
+    """All tiles busy and heavy: heavy list + busy list together are longer than the tile count
+    (a tile sits on both), which must not drop entries."""
+    mesh, texs = synthetic
+    gpu, cpu = render_pair(256, 64, mesh, texs, pipe, 0.0, 0.0)
+    assert_parity(gpu, cpu, pipe)
+    gpu, cpu = render_pair(384, 200, mesh, texs, pipe, 0.9, -0.4)
+    assert_parity(gpu, cpu, pipe)

@@ -137,20 +137,26 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
         // lane of every wave shares ONE list counter (a single word takes ~90 atomics per
         // microsecond), so the wave reserves a range with one atomic per trip and its lanes take
         // consecutive entries.
-        uint32_t firsts = 0u;
+        // ... and likewise on the heavy list when its HEAVY_AT-th record arrives.
 #pragma unroll
-        for (int k = 0; k < PAIRS; k++) {
-            const unsigned long long mask = __ballot(own[k] >= 0 && slot[k] == 0u);
-            pos[k] = firsts + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            firsts += (uint32_t)__builtin_popcountll(mask);
-        }
-        if (firsts) {
-            uint32_t base = 0u;
-            if (lane == 0u) base = atomicAdd(a.busy_n, firsts);
-            base = (uint32_t)__shfl((int)base, 0, 64);
+        for (int which = 0; which < 2; which++) {
+            const uint32_t at = which == 0 ? 0u : HEAVY_AT - 1u;
+            uint32_t *list = which == 0 ? a.busy_list : a.heavy_list;
+            uint32_t firsts = 0u;
 #pragma unroll
-            for (int k = 0; k < PAIRS; k++)
-                if (own[k] >= 0 && slot[k] == 0u) a.busy_list[base + pos[k]] = (uint32_t)tile[k];
+            for (int k = 0; k < PAIRS; k++) {
+                const unsigned long long mask = __ballot(own[k] >= 0 && slot[k] == at);
+                pos[k] = firsts + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                firsts += (uint32_t)__builtin_popcountll(mask);
+            }
+            if (firsts) {
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(a.busy_n + which, firsts);
+                base = (uint32_t)__shfl((int)base, 0, 64);
+#pragma unroll
+                for (int k = 0; k < PAIRS; k++)
+                    if (own[k] >= 0 && slot[k] == at) list[base + pos[k]] = (uint32_t)tile[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < PAIRS; k++) {
@@ -263,11 +269,12 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     __shared__ uint2 s_key[TILE_W * TILE_H];
     __shared__ uint4 s_rec[NMAX * P];
 
-    // The launch has 2 * n_tiles blocks.
-    //   * Blocks [0, n_busy) run the list k_setup built of tiles with at least one polygon: the
-    //     long, VALU-bound ones.  They come first so that the machine is full of them from the
-    //     first microsecond (a row-major walk meets the last busy tile at its very end).
-    //   * Blocks [n_tiles, 2 n_tiles) are the "sweep": every tile is visited once in a hashed
+    // The launch has 3 * n_tiles blocks (heavy list + busy list + sweep, each at most n_tiles).
+    //   * The first blocks run the lists k_setup built of tiles with at least one polygon: the
+    //     long, VALU-bound ones, heaviest (>= HEAVY_AT polygons) first.  They come first so that
+    //     the machine is full of them from the first microsecond (a row-major walk meets the last
+    //     busy tile at its very end) and the longest ones do not form the tail.
+    //   * The next n_tiles blocks are the "sweep": every tile is visited once in a hashed
     //     order (neighbouring tiles scattered over the launch); the sweep streams the cleared
     //     value of the empty tiles -- short, HBM-bound work -- and zeroes the ping-pong counters
     //     for the next pass.
@@ -275,22 +282,30 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     // busy blocks issue the sweep stores themselves, was 5-10 % slower.  Any order is correct.
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x >= n_tiles) {
-        const uint32_t i = blockIdx.x - n_tiles;
+    // busy part: heavy tiles (>= HEAVY_AT polygons) first, then the remaining busy tiles; the
+    // sweep follows immediately; workgroups past n_heavy + n_light + n_tiles have nothing to do
+    // (the launch is sized for the worst case, 3 n_tiles)
+    const uint32_t n_light = a.busy_n[0], n_heavy = a.busy_n[1];
+    if (blockIdx.x >= n_heavy + n_light) {
+        const uint32_t i = blockIdx.x - (n_heavy + n_light);
+        if (i >= n_tiles) return;
         const uint32_t t = scatter_tile(i, n_tiles, a.scatter_bits);
         if (tid == 0u) {
             a.tile_count_next[t] = 0u;
-            if (i == 0u) *a.busy_n_next = 0u;
+            if (i == 0u) {
+                a.busy_n_next[0] = 0u;
+                a.busy_n_next[1] = 0u;
+            }
         }
         if (a.tile_count[t] == 0u && a.fresh)
             write_cleared_tile<DEPTH>(a, (int32_t)(t % a.frame.ntx) * TILE_W,
                                       (a.frame.ty_base + (int32_t)(t / a.frame.ntx)) * TILE_H);
         return;
     }
-    if (blockIdx.x >= *a.busy_n) return;
-
-    const uint32_t tile = a.busy_list[blockIdx.x];
+    const bool heavy_part = blockIdx.x < n_heavy;
+    const uint32_t tile = heavy_part ? a.heavy_list[blockIdx.x] : a.busy_list[blockIdx.x - n_heavy];
     uint32_t n = a.tile_count[tile];
+    if (!heavy_part && n >= HEAVY_AT) return;  // rendered by its heavy-list workgroup
     if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
@@ -718,7 +733,7 @@ int launch_tile(int fs, const TileArgs &a, hipStream_t st)
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
-    const dim3 grid(2u * n_tiles), block(256);
+    const dim3 grid(3u * n_tiles), block(256);
     switch (fs) {
     case FS_DEFAULT: hipLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, a); break;
     case FS_PHONG: hipLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, a); break;

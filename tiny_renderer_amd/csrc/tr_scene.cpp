@@ -110,7 +110,8 @@ struct tr_scene {
     struct BinState {
         uint32_t *count[2] = { nullptr, nullptr };
         uint32_t *list[2] = { nullptr, nullptr };
-        uint32_t *nbusy = nullptr;  // two words
+        uint32_t *heavy[2] = { nullptr, nullptr };
+        uint32_t *nbusy = nullptr;  // two words (busy, heavy) per set
         int cur = 0;
     } bin_color, bin_depth;
     Piece *d_bins = nullptr;     // n_tiles_full x bin_cap records of rec_pieces x 16 B
@@ -367,7 +368,8 @@ int run_pass(tr_scene *s, const PassDesc &p)
     tr_scene::BinState &bs = depth_pass ? s->bin_depth : s->bin_color;
     sa.tile_count = bs.count[bs.cur];
     sa.busy_list = bs.list[bs.cur];
-    sa.busy_n = bs.nbusy + bs.cur;
+    sa.heavy_list = bs.heavy[bs.cur];
+    sa.busy_n = bs.nbusy + 2 * bs.cur;
     sa.bins = s->d_bins;
     sa.bin_cap = s->bin_cap;
     sa.rec_pieces = s->rec_pieces;
@@ -385,9 +387,10 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.rec_pieces = s->rec_pieces;
     ta.tile_count = bs.count[bs.cur];
     ta.busy_list = bs.list[bs.cur];
-    ta.busy_n = bs.nbusy + bs.cur;
+    ta.heavy_list = bs.heavy[bs.cur];
+    ta.busy_n = bs.nbusy + 2 * bs.cur;
     ta.tile_count_next = bs.count[bs.cur ^ 1];
-    ta.busy_n_next = bs.nbusy + (bs.cur ^ 1);
+    ta.busy_n_next = bs.nbusy + 2 * (bs.cur ^ 1);
     ta.frame = frame;
     ta.u = du;
     ta.tex = s->tex;
@@ -450,6 +453,7 @@ void destroy(tr_scene *s)
         for (int k = 0; k < 2; k++) {
             dev_free(b->count[k]);
             dev_free(b->list[k]);
+            dev_free(b->heavy[k]);
         }
         dev_free(b->nbusy);
     }
@@ -562,10 +566,11 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         for (int k = 0; k < 2; k++) {
             if ((st = dev_alloc(&b->count[k], nt))) return st;
             if ((st = dev_alloc(&b->list[k], nt))) return st;
+            if ((st = dev_alloc(&b->heavy[k], nt))) return st;
             HIP_TRY(hipMemset(b->count[k], 0, nt * 4));
         }
-        if ((st = dev_alloc(&b->nbusy, 2))) return st;
-        HIP_TRY(hipMemset(b->nbusy, 0, 8));
+        if ((st = dev_alloc(&b->nbusy, 4))) return st;
+        HIP_TRY(hipMemset(b->nbusy, 0, 16));
     }
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
     uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow

@@ -86,6 +86,9 @@ constexpr int REC_PIECES_LARGE = 9;  // 144 B
 // Records a tile keeps resident in LDS (8 KiB worth = 85 / 56 records); larger bins take the
 // chunked path.  With the 16 KiB of keys a workgroup stays under 25 KiB: six fit in a CU's LDS.
 constexpr int LDS_REC_BYTES = 8192;
+// A tile whose bin reaches this many polygons is "heavy": the tile kernel starts heavy tiles
+// first (longest-processing-time-first packing of the launch).
+constexpr uint32_t HEAVY_AT = 12;
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {
@@ -155,8 +158,9 @@ struct SetupArgs {
     DevFrame frame;
     DevUniforms u;
     uint32_t *tile_count;
-    uint32_t *busy_list;  // tiles that received their first record, in arrival order
-    uint32_t *busy_n;     // length of busy_list
+    uint32_t *busy_list;   // tiles that received their first record, in arrival order
+    uint32_t *heavy_list;  // tiles that received their HEAVY_AT-th record: k_tile starts these first
+    uint32_t *busy_n;      // [0] length of busy_list, [1] length of heavy_list
     Piece *bins;        // n_tiles x bin_cap records of rec_pieces x 16 B
     uint32_t bin_cap;
     uint32_t rec_pieces;
@@ -172,7 +176,8 @@ struct TileArgs {
     // `busy_list` / `busy_n` (filled by its k_setup) and zeroes the other set for the next pass.
     const uint32_t *tile_count;
     const uint32_t *busy_list;
-    const uint32_t *busy_n;
+    const uint32_t *heavy_list;
+    const uint32_t *busy_n;  // [0] busy tiles, [1] heavy tiles
     uint32_t *tile_count_next;
     uint32_t *busy_n_next;
     DevFrame frame;
