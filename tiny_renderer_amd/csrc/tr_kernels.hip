@@ -43,19 +43,24 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 // -----------------------------------------------------------------------------------------
 // k_setup
 // -----------------------------------------------------------------------------------------
+constexpr uint32_t SETUP_POLYS = 16;  // polygons per 64-lane workgroup of k_setup
+
 template <int VS>
 __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
 {
     constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    __shared__ uint4 s_rec[64 * P];
+    __shared__ uint4 s_rec[SETUP_POLYS * P];
     __shared__ int32_t s_excl[64], s_tx0[64], s_ty0[64], s_ntx[64];
 
+    // A wave takes only SETUP_POLYS polygons (the other lanes idle through the short vertex
+    // stage) but all 64 lanes share the binning below: the polygons of one wave can span hundreds
+    // of tiles, and the wave with the most (polygon, tile) pairs is the kernel's critical path.
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = blockIdx.x * 64u + lane;
+    const uint32_t t = blockIdx.x * SETUP_POLYS + lane;
 
     int32_t tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
     uint32_t err = 0;
-    if (t < a.mesh.n_tri) {
+    if (lane < SETUP_POLYS && t < a.mesh.n_tri) {
         RasterRec r;
         float v[VARY_STRIDE];
 #pragma unroll
@@ -715,7 +720,7 @@ int launch_setup(int vs, const SetupArgs &a, hipStream_t st)
 {
     if (a.mesh.n_tri == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
-    const dim3 grid((a.mesh.n_tri + 63u) / 64u), block(64);
+    const dim3 grid((a.mesh.n_tri + SETUP_POLYS - 1u) / SETUP_POLYS), block(64);
     switch (vs) {
     case VS_DEFAULT: hipLaunchKernelGGL(k_setup<VS_DEFAULT>, grid, block, 0, st, a); break;
     case VS_PHONG: hipLaunchKernelGGL(k_setup<VS_PHONG>, grid, block, 0, st, a); break;
