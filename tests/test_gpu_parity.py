@@ -252,3 +252,27 @@ def test_every_tile_heavy(synthetic, pipe):
     assert_parity(gpu, cpu, pipe)
     gpu, cpu = render_pair(384, 200, mesh, texs, pipe, 0.9, -0.4)
     assert_parity(gpu, cpu, pipe)
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow"])
+def test_frames_in_flight(small_synthetic, pipe):
+    """Consecutive frames are pipelined (the setup kernel of frame f+1 overlaps the tile kernel of
+    frame f, with triple-buffered counters and double-buffered bins): a burst of frames with a
+    moving camera and no readback in between must end with exactly the last frame."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 640, 400
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True)
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    for burst in (1, 2, 3, 7):
+        for f in range(burst):
+            gpu.clear()
+            gpu.set_light_direction(H.light(0.1 * f - 0.3 * burst))
+            gpu.set_camera(*H.camera(0.37 * f + burst))
+            gpu.render()
+        cpu.clear()
+        cpu.set_light_direction(H.light(0.1 * (burst - 1) - 0.3 * burst))
+        cpu.set_camera(*H.camera(0.37 * (burst - 1) + burst))
+        assert cpu.render() == 0
+        assert_parity(gpu, cpu, pipe)

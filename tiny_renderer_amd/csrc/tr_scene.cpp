@@ -107,14 +107,26 @@ struct tr_scene {
     // reads set `cur`, its tile kernel zeroes the other set for the next pass of the same kind.
     // Colour passes (the scene's band) and depth passes (always the whole frame) have different
     // tile grids, hence a state each.
+    // Three sets: while the tile kernel of pass q reads set q % 3 and zeroes set (q + 2) % 3, the
+    // setup kernel of pass q + 1 (running beside it on the setup stream) fills set (q + 1) % 3.
     struct BinState {
-        uint32_t *count[2] = { nullptr, nullptr };
-        uint32_t *list[2] = { nullptr, nullptr };
-        uint32_t *heavy[2] = { nullptr, nullptr };
+        uint32_t *count[3] = { nullptr, nullptr, nullptr };
+        uint32_t *list[3] = { nullptr, nullptr, nullptr };
+        uint32_t *heavy[3] = { nullptr, nullptr, nullptr };
         uint32_t *nbusy = nullptr;  // two words (busy, heavy) per set
-        int cur = 0;
+        uint64_t seq = 0;           // passes of this kind issued so far
     } bin_color, bin_depth;
-    Piece *d_bins = nullptr;     // n_tiles_full x bin_cap records of rec_pieces x 16 B
+    // Record bins, double buffered by global pass number: pass p's setup fills bins[p % 2] while
+    // pass p - 1's tile kernel is still reading bins[(p - 1) % 2].
+    Piece *d_bins[2] = { nullptr, nullptr };  // each n_tiles_full x bin_cap records of rec_pieces x 16 B
+    // Pass pipelining: k_setup of pass p runs on `setup_stream`, ordered after the tile kernel of
+    // pass p - 2 (which frees its bins and zeroed its counters) and before the tile kernel of pass p
+    // on the main stream.  It needs only frame constants, so it overlaps the tile kernel of pass
+    // p - 1: consecutive frames are in flight together, like any renderer's.
+    hipStream_t setup_stream = nullptr;
+    hipEvent_t ev_setup[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_tile[4] = { nullptr, nullptr, nullptr, nullptr };
+    uint64_t pass_seq = 0;
     uint32_t bin_cap = 0;        // records per tile; grown on overflow
     uint32_t rec_pieces = 0;
     uint32_t *d_bin_need = nullptr;
@@ -180,21 +192,22 @@ hipEvent_t take_event(tr_scene *s)
 
 struct Timed {
     tr_scene *s;
+    hipStream_t st;
     EventPair ep;
     bool on;
-    Timed(tr_scene *sc, int kernel) : s(sc), on(false)
+    Timed(tr_scene *sc, int kernel, hipStream_t stream = nullptr) : s(sc), st(stream ? stream : sc->stream), on(false)
     {
         ep.kernel = kernel;
         ep.a = ep.b = nullptr;
         if (s->profiling && s->events.size() < (1u << 20)) {
             ep.a = take_event(s);
             ep.b = take_event(s);
-            if (ep.a && ep.b && hipEventRecord(ep.a, s->stream) == hipSuccess) on = true;
+            if (ep.a && ep.b && hipEventRecord(ep.a, st) == hipSuccess) on = true;
         }
     }
     ~Timed()
     {
-        if (on && hipEventRecord(ep.b, s->stream) == hipSuccess) s->events.push_back(ep);
+        if (on && hipEventRecord(ep.b, st) == hipSuccess) s->events.push_back(ep);
     }
 };
 
@@ -263,11 +276,15 @@ int recover_from_overflow(tr_scene *s)
     while (cap < need) cap *= 2;
     if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
     if (cap < need) cap = need;
-    if (cap * (uint64_t)s->n_tiles_full * s->rec_pieces * 16ull > (64ull << 30))
+    if (2ull * cap * (uint64_t)s->n_tiles_full * s->rec_pieces * 16ull > (64ull << 30))
         return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 64 GiB");
-    dev_free(s->d_bins);
+    HIP_TRY(hipStreamSynchronize(s->setup_stream));
     s->bin_cap = (uint32_t)cap;
-    int st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces);
+    int st = TR_OK;
+    for (int k = 0; k < 2 && st == TR_OK; k++) {
+        dev_free(s->d_bins[k]);
+        st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces);
+    }
     if (st != TR_OK) return st;
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
@@ -366,31 +383,38 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.frame = frame;
     sa.u = du;
     tr_scene::BinState &bs = depth_pass ? s->bin_depth : s->bin_color;
-    sa.tile_count = bs.count[bs.cur];
-    sa.busy_list = bs.list[bs.cur];
-    sa.heavy_list = bs.heavy[bs.cur];
-    sa.busy_n = bs.nbusy + 2 * bs.cur;
-    sa.bins = s->d_bins;
+    const int set_cur = (int)(bs.seq % 3), set_zero = (int)((bs.seq + 2) % 3);
+    const uint64_t p_seq = s->pass_seq;
+    Piece *bins = s->d_bins[p_seq % 2];
+    sa.tile_count = bs.count[set_cur];
+    sa.busy_list = bs.list[set_cur];
+    sa.heavy_list = bs.heavy[set_cur];
+    sa.busy_n = bs.nbusy + 2 * set_cur;
+    sa.bins = bins;
     sa.bin_cap = s->bin_cap;
     sa.rec_pieces = s->rec_pieces;
     sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
+    // setup on its own stream: after the tile kernel of pass p - 2, before the tile kernel of pass p
+    if (p_seq >= 2) HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - 2) % 4], 0));
     {
-        Timed t(s, K_SETUP);
-        int rc = launch_setup(p.vs, sa, s->stream);
+        Timed t(s, K_SETUP, s->setup_stream);
+        int rc = launch_setup(p.vs, sa, s->setup_stream);
         if (rc) return launch_status(rc, "k_setup");
     }
+    HIP_TRY(hipEventRecord(s->ev_setup[p_seq % 4], s->setup_stream));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[p_seq % 4], 0));
 
     TileArgs ta;
-    ta.bins = s->d_bins;
+    ta.bins = bins;
     ta.bin_cap = s->bin_cap;
     ta.rec_pieces = s->rec_pieces;
-    ta.tile_count = bs.count[bs.cur];
-    ta.busy_list = bs.list[bs.cur];
-    ta.heavy_list = bs.heavy[bs.cur];
-    ta.busy_n = bs.nbusy + 2 * bs.cur;
-    ta.tile_count_next = bs.count[bs.cur ^ 1];
-    ta.busy_n_next = bs.nbusy + 2 * (bs.cur ^ 1);
+    ta.tile_count = bs.count[set_cur];
+    ta.busy_list = bs.list[set_cur];
+    ta.heavy_list = bs.heavy[set_cur];
+    ta.busy_n = bs.nbusy + 2 * set_cur;
+    ta.tile_count_next = bs.count[set_zero];
+    ta.busy_n_next = bs.nbusy + 2 * set_zero;
     ta.frame = frame;
     ta.u = du;
     ta.tex = s->tex;
@@ -410,7 +434,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
         int rc = launch_tile(p.fs, ta, s->stream);
         if (rc) return launch_status(rc, "k_tile");
     }
-    bs.cur ^= 1;
+    HIP_TRY(hipEventRecord(s->ev_tile[p_seq % 4], s->stream));
+    bs.seq++;
+    s->pass_seq++;
     return TR_OK;
 }
 
@@ -449,15 +475,22 @@ void destroy(tr_scene *s)
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     dev_free(s->d_tri);
     for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
+    if (s->setup_stream) (void)hipStreamSynchronize(s->setup_stream);
+    for (int k = 0; k < 4; k++) {
+        if (s->ev_setup[k]) (void)hipEventDestroy(s->ev_setup[k]);
+        if (s->ev_tile[k]) (void)hipEventDestroy(s->ev_tile[k]);
+    }
+    if (s->setup_stream) (void)hipStreamDestroy(s->setup_stream);
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             dev_free(b->count[k]);
             dev_free(b->list[k]);
             dev_free(b->heavy[k]);
         }
         dev_free(b->nbusy);
     }
-    dev_free(s->d_bins);
+    dev_free(s->d_bins[0]);
+    dev_free(s->d_bins[1]);
     dev_free(s->d_bin_need);
     dev_free(s->d_z);
     dev_free(s->d_shadow);
@@ -563,14 +596,14 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     // bins
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
         const size_t nt = (b == &s->bin_color) ? s->n_tiles : s->n_tiles_full;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             if ((st = dev_alloc(&b->count[k], nt))) return st;
             if ((st = dev_alloc(&b->list[k], nt))) return st;
             if ((st = dev_alloc(&b->heavy[k], nt))) return st;
             HIP_TRY(hipMemset(b->count[k], 0, nt * 4));
         }
-        if ((st = dev_alloc(&b->nbusy, 4))) return st;
-        HIP_TRY(hipMemset(b->nbusy, 0, 16));
+        if ((st = dev_alloc(&b->nbusy, 6))) return st;
+        HIP_TRY(hipMemset(b->nbusy, 0, 24));
     }
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
     uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
@@ -578,7 +611,13 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if (cap < 64) cap = 64;
     s->bin_cap = (uint32_t)cap;
     s->rec_pieces = (pipe == P_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    if ((st = dev_alloc(&s->d_bins, (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
+    for (int k = 0; k < 2; k++)
+        if ((st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
+    HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 4; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_setup[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_tile[k], hipEventDisableTiming));
+    }
     HIP_TRY(hipMemset(s->d_bin_need, 0, 4));
 
     // render targets; Buffer::new / Scene::new zero-fill them (shader.rs:46-47, scene.rs:71)
