@@ -58,16 +58,18 @@ TEXEL_BYTES = {"default": 3, "phong": 3, "shadow": 3, "normal_map": 6, "darboux"
 
 
 def algorithmic_bytes(W, H, pipe, stats):
-    """bytes_alg = W*H*C + F_cov*4 + F_acc*(7+S) + T_kept*132 (+ shadow terms)."""
+    """bytes_alg = W*H*C + F_cov*4 + F_acc*(7+S) + T_kept*132 (+ shadow terms),
+    split by the kernel that owns the bytes: {"k_tile": colour pass, "k_tile_depth": depth pass}."""
     two_pass = pipe in ("shadow", "occlusion")
     color = stats[1] if two_pass else stats[0]
-    C = 11 if two_pass else 7
     S = TEXEL_BYTES[pipe]
-    b = W * H * C + color["frag_covered"] * 4 + color["frag_accept"] * (7 + S) + color["tri_kept"] * 132
+    out = {"k_tile": int(W * H * 7 + color["frag_covered"] * 4 + color["frag_accept"] * (7 + S)
+                         + color["tri_kept"] * 132)}
     if two_pass:
-        b += stats[0]["frag_covered"] * 4 + stats[0]["shadow_upd"] * 4 + color["frag_accept"] * 4
-        b += stats[0]["tri_kept"] * 132
-    return int(b)
+        out["k_tile"] += int(color["frag_accept"] * 4)          # one shadow-buffer gather per accept
+        out["k_tile_depth"] = int(W * H * 4 + stats[0]["frag_covered"] * 4 + stats[0]["shadow_upd"] * 4
+                                  + stats[0]["tri_kept"] * 132)  # clear + read + update of the shadow buffer
+    return out
 
 
 def main():
@@ -221,12 +223,15 @@ def main():
                                       "(C restatement of the reference, single-threaded like it), "
                                       "%.3f s/frame" % (frames, per_frame)}
 
-        bytes_alg = algorithmic_bytes(W, H, pipe, stats)
-        tile = prof.get("k_tile")
+        bytes_by_kernel = algorithmic_bytes(W, H, pipe, stats)
+        # the dominant kernel = the one with the larger share of device time
+        dom = max(bytes_by_kernel, key=lambda k: prof.get(k, {}).get("total_ms", 0.0))
+        bytes_alg = bytes_by_kernel[dom]
+        tile = prof.get(dom)
         roofline = None
         if tile and tile["launches"]:
             avg_s = tile["total_ms"] / tile["launches"] / 1e3
-            # one k_tile launch = one frame (or one band of it): its share of the frame's bytes
+            # one launch = one pass over the frame (or over this rank's band of it)
             ach = bytes_alg / world / avg_s / 1e9
             traffic = None
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -235,12 +240,14 @@ def main():
                     # HBM bytes of one k_tile launch from the rocprofv3 PMC passes of this workload
                     # (FETCH_SIZE x2 + WRITE_SIZE, see profiles/pmc_traffic.json); null when this
                     # workload has not been profiled
-                    traffic = json.load(open(tf)).get(workload, {}).get("hbm_bytes_per_launch")
+                    entry = json.load(open(tf)).get(workload, {})
+                    traffic = entry.get("hbm_bytes_per_launch") if entry.get("kernel") == dom else None
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_alg // world}
+                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_alg // world,
+                        "algorithmic_bytes_per_frame": sum(bytes_by_kernel.values())}
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": "Mpixels/s shaded (z-test + Phong) at 4096x4096",
