@@ -399,10 +399,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     if (p_seq >= 2) HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - 2) % 4], 0));
     {
         Timed t(s, K_SETUP, s->setup_stream);
-        int rc = launch_setup(p.vs, sa, s->setup_stream);
+        int rc = launch_setup(p.vs, sa, s->setup_stream, s->ev_setup[p_seq % 4]);
         if (rc) return launch_status(rc, "k_setup");
     }
-    HIP_TRY(hipEventRecord(s->ev_setup[p_seq % 4], s->setup_stream));
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[p_seq % 4], 0));
 
     TileArgs ta;
@@ -431,10 +430,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     while ((1u << ta.scatter_bits) < frame.ntx * frame.nty) ta.scatter_bits++;
     {
         Timed t(s, depth_pass ? K_TILE_DEPTH : K_TILE);
-        int rc = launch_tile(p.fs, ta, s->stream);
+        int rc = launch_tile(p.fs, ta, s->stream, s->ev_tile[p_seq % 4]);
         if (rc) return launch_status(rc, "k_tile");
     }
-    HIP_TRY(hipEventRecord(s->ev_tile[p_seq % 4], s->stream));
     bs.seq++;
     s->pass_seq++;
     return TR_OK;
