@@ -9,9 +9,11 @@
 
 namespace tr {
 
-// `done` (may be null) is signalled by the kernel's own completion: no separate event packet.
-int launch_setup(int vs_kind, const SetupArgs &a, hipStream_t st, hipEvent_t done);
-int launch_tile(int fs_kind, const TileArgs &a, hipStream_t st, hipEvent_t done);
+// `start` / `done` (may be null) are attached to the kernel's own dispatch packet: `done` is
+// signalled by the kernel's completion without a separate event packet, and the pair brackets
+// exactly the kernel's execution when both are timing events.
+int launch_setup(int vs_kind, const SetupArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done);
+int launch_tile(int fs_kind, const TileArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done);
 int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
                     uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st);

@@ -717,38 +717,38 @@ __global__ __launch_bounds__(256) void k_selftest(const float *x, const float *d
 int rec_pieces_for_vs(int vs) { return vs == VS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 int rec_pieces_for_fs(int fs) { return fs == FS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 
-int launch_setup(int vs, const SetupArgs &a, hipStream_t st, hipEvent_t done)
+int launch_setup(int vs, const SetupArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     if (a.mesh.n_tri == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
     const dim3 grid((a.mesh.n_tri + SETUP_POLYS - 1u) / SETUP_POLYS), block(64);
     switch (vs) {
-    case VS_DEFAULT: hipExtLaunchKernelGGL(k_setup<VS_DEFAULT>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case VS_PHONG: hipExtLaunchKernelGGL(k_setup<VS_PHONG>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case VS_PLAIN: hipExtLaunchKernelGGL(k_setup<VS_PLAIN>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case VS_DARBOUX: hipExtLaunchKernelGGL(k_setup<VS_DARBOUX>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case VS_DEPTH: hipExtLaunchKernelGGL(k_setup<VS_DEPTH>, grid, block, 0, st, nullptr, done, 0, a); break;
+    case VS_DEFAULT: hipExtLaunchKernelGGL(k_setup<VS_DEFAULT>, grid, block, 0, st, start, done, 0, a); break;
+    case VS_PHONG: hipExtLaunchKernelGGL(k_setup<VS_PHONG>, grid, block, 0, st, start, done, 0, a); break;
+    case VS_PLAIN: hipExtLaunchKernelGGL(k_setup<VS_PLAIN>, grid, block, 0, st, start, done, 0, a); break;
+    case VS_DARBOUX: hipExtLaunchKernelGGL(k_setup<VS_DARBOUX>, grid, block, 0, st, start, done, 0, a); break;
+    case VS_DEPTH: hipExtLaunchKernelGGL(k_setup<VS_DEPTH>, grid, block, 0, st, start, done, 0, a); break;
     default: return (int)hipErrorInvalidValue;
     }
     TR_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_tile(int fs, const TileArgs &a, hipStream_t st, hipEvent_t done)
+int launch_tile(int fs, const TileArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
     const dim3 grid(3u * n_tiles), block(256);
     switch (fs) {
-    case FS_DEFAULT: hipExtLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_PHONG: hipExtLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_NORMAL_MAP: hipExtLaunchKernelGGL(k_tile<FS_NORMAL_MAP>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_SPECULAR: hipExtLaunchKernelGGL(k_tile<FS_SPECULAR>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_DARBOUX: hipExtLaunchKernelGGL(k_tile<FS_DARBOUX>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_SHADOW2: hipExtLaunchKernelGGL(k_tile<FS_SHADOW2>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_OCCLUSION2: hipExtLaunchKernelGGL(k_tile<FS_OCCLUSION2>, grid, block, 0, st, nullptr, done, 0, a); break;
-    case FS_DEPTH: hipExtLaunchKernelGGL(k_tile<FS_DEPTH>, grid, block, 0, st, nullptr, done, 0, a); break;
+    case FS_DEFAULT: hipExtLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_PHONG: hipExtLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_NORMAL_MAP: hipExtLaunchKernelGGL(k_tile<FS_NORMAL_MAP>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_SPECULAR: hipExtLaunchKernelGGL(k_tile<FS_SPECULAR>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_DARBOUX: hipExtLaunchKernelGGL(k_tile<FS_DARBOUX>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_SHADOW2: hipExtLaunchKernelGGL(k_tile<FS_SHADOW2>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_OCCLUSION2: hipExtLaunchKernelGGL(k_tile<FS_OCCLUSION2>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_DEPTH: hipExtLaunchKernelGGL(k_tile<FS_DEPTH>, grid, block, 0, st, start, done, 0, a); break;
     default: return (int)hipErrorInvalidValue;
     }
     TR_LAUNCH_CHECK();

@@ -397,10 +397,16 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.err = s->d_err;
     // setup on its own stream: after the tile kernel of pass p - 2, before the tile kernel of pass p
     if (p_seq >= 2) HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - 2) % 4], 0));
-    {
-        Timed t(s, K_SETUP, s->setup_stream);
-        int rc = launch_setup(p.vs, sa, s->setup_stream, s->ev_setup[p_seq % 4]);
+    if (!s->profiling) {
+        int rc = launch_setup(p.vs, sa, s->setup_stream, nullptr, s->ev_setup[p_seq % 4]);
         if (rc) return launch_status(rc, "k_setup");
+    } else {
+        // profiling: timing events on the dispatch itself, then the pipeline's event separately
+        EventPair ep = { take_event(s), take_event(s), K_SETUP };
+        int rc = launch_setup(p.vs, sa, s->setup_stream, ep.a, ep.b);
+        if (rc) return launch_status(rc, "k_setup");
+        s->events.push_back(ep);
+        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % 4], s->setup_stream));
     }
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[p_seq % 4], 0));
 
@@ -428,10 +434,15 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
     ta.scatter_bits = 1;
     while ((1u << ta.scatter_bits) < frame.ntx * frame.nty) ta.scatter_bits++;
-    {
-        Timed t(s, depth_pass ? K_TILE_DEPTH : K_TILE);
-        int rc = launch_tile(p.fs, ta, s->stream, s->ev_tile[p_seq % 4]);
+    if (!s->profiling) {
+        int rc = launch_tile(p.fs, ta, s->stream, nullptr, s->ev_tile[p_seq % 4]);
         if (rc) return launch_status(rc, "k_tile");
+    } else {
+        EventPair ep = { take_event(s), take_event(s), depth_pass ? K_TILE_DEPTH : K_TILE };
+        int rc = launch_tile(p.fs, ta, s->stream, ep.a, ep.b);
+        if (rc) return launch_status(rc, "k_tile");
+        s->events.push_back(ep);
+        HIP_TRY(hipEventRecord(s->ev_tile[p_seq % 4], s->stream));
     }
     bs.seq++;
     s->pass_seq++;
