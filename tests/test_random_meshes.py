@@ -1,0 +1,91 @@
+"""Random polygon soups with deliberate depth ties (duplicated, coplanar and edge-sharing polygons,
+coarse coordinates): the order-independent resolve -- largest z, ties to the lowest polygon index
+for colour passes and to the highest for depth passes -- must equal the reference's serial loop.
+CPU: the emulation (bins visited in reverse order) against the oracle, driven by hypothesis.
+GPU: the same generator with fixed seeds through the C ABI."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import oracle as O
+from tests import emul_bind as E
+from tests import helpers as H
+
+F = np.float32
+
+
+def soup(seed, n_tri, grid):
+    """n_tri polygons on a coarse lattice (many exact ties), facing either way."""
+    rng = np.random.default_rng(seed)
+    pts = (rng.integers(-grid, grid + 1, size=(n_tri, 3, 3)).astype(F) / F(grid)) * F(0.9)
+    pts[..., 2] = np.round(pts[..., 2] * 2) / 2 * F(0.5)           # few distinct depths
+    dup = rng.random(n_tri) < 0.3                                   # exact duplicates of earlier polygons
+    for i in np.nonzero(dup)[0]:
+        if i:
+            pts[i] = pts[rng.integers(0, i)]
+    share = rng.random(n_tri) < 0.3                                 # share an edge with the previous polygon
+    for i in np.nonzero(share)[0]:
+        if i:
+            pts[i, :2] = pts[i - 1, 1:]
+    pos = pts.reshape(-1, 3)
+    nrm = rng.standard_normal((n_tri * 3, 3)).astype(F)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tex = np.concatenate([rng.uniform(0.05, 0.95, (n_tri * 3, 2)).astype(F), np.zeros((n_tri * 3, 1), F)], 1)
+    idx = np.arange(n_tri * 3, dtype=np.uint32).reshape(n_tri, 3).repeat(3, axis=1)
+    texs = [rng.integers(0, 256, (32, 32, 3), dtype=np.uint8) for _ in range(4)]
+    return {"pos": pos, "tex": tex, "nrm": nrm, "idx": idx}, texs
+
+
+def oracle_frame(W, Hh, mesh, texs, pipe, ca, la):
+    s = O.Scene(W, Hh, mesh, texs, pipe)
+    s.clear()
+    s.set_light_direction(H.light(la))
+    s.set_camera(*H.camera(ca))
+    err = s.render()
+    return err, s
+
+
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), n_tri=st.integers(1, 60), grid=st.sampled_from([2, 3, 5, 9]),
+       pipe=st.sampled_from(["default", "phong", "shadow", "occlusion"]),
+       ca=st.sampled_from([0.0, 0.3, 3.14159]), size=st.sampled_from([(96, 64), (130, 50), (257, 33)]))
+def test_resolve_matches_serial_order_cpu(seed, n_tri, grid, pipe, ca, size):
+    mesh, texs = soup(seed, n_tri, grid)
+    W, Hh = size
+    err, s = oracle_frame(W, Hh, mesh, texs, pipe, ca, 0.4)
+    if err:
+        return  # the reference would have panicked (e.g. w == 0): no defined result
+    e, z, sh, fb, win = E.render(W, Hh, mesh, texs, pipe, H.light(0.4), H.camera(ca))
+    assert e == 0
+    assert np.array_equal(win, s.winner_u32())
+    assert np.array_equal(z.view(np.uint32), s.z_f32().view(np.uint32))
+    assert np.array_equal(fb, s.get_frame_buffer())
+    if pipe in ("shadow", "occlusion"):
+        assert np.array_equal(sh.view(np.uint32), s.shadow_f32().view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_resolve_matches_serial_order_gpu(built, seed):
+    import tiny_renderer_amd as T
+    rng = np.random.default_rng(1000 + seed)
+    n_tri = int(rng.integers(1, 400))
+    grid = int(rng.choice([2, 3, 5, 9]))
+    pipe = ["default", "phong", "shadow", "occlusion", "darboux", "normal_map"][seed % 6]
+    W, Hh = [(96, 64), (130, 50), (257, 33), (640, 480)][seed % 4]
+    mesh, texs = soup(seed, n_tri, grid)
+    ca = [0.0, 0.3, 3.14159][seed % 3]
+    err, s = oracle_frame(W, Hh, mesh, texs, pipe, ca, 0.4)
+    if err:
+        pytest.skip("the reference would panic on this soup")
+    g = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True)
+    g.clear()
+    g.set_light_direction(H.light(0.4))
+    g.set_camera(*H.camera(ca))
+    g.render()
+    fb = g.get_frame_buffer()
+    assert np.array_equal(g.read_winner_u32(), s.winner_u32())
+    assert np.array_equal(g.read_z_f32().view(np.uint32), s.z_f32().view(np.uint32))
+    assert np.array_equal(fb, s.get_frame_buffer())
+    if pipe in ("shadow", "occlusion"):
+        assert np.array_equal(g.read_shadow_f32().view(np.uint32), s.shadow_f32().view(np.uint32))

@@ -17,8 +17,6 @@ namespace tr {
 // Vertex stage
 // ---------------------------------------------------------------------------------------------
 
-TR_HD vec3 load3(const float *p, uint32_t i) { return make3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
-
 // should_cull_face, shader.rs:116-124 (object space, orthographic approximation)
 TR_HD bool cull_face(vec3 p0, vec3 p1, vec3 p2, const float *cam)
 {
