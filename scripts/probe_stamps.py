@@ -13,18 +13,16 @@ for _ in range(5):
     s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()
 s.sync()
 st = s.debug_tile_stamps().astype(np.int64)
-t0 = st[:, 0].min()
+t0 = st[st[:, 2] > 0, 0].min()  # sweep blocks leave no stamp
 start, end, n = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, st[:, 2]   # us
 dur = end - start
 busy = n > 0
 stage = (st[:, 4] - st[:, 0]) / 100.0; cover = (st[:, 5] - st[:, 4]) / 100.0; shade = (st[:, 1] - st[:, 5]) / 100.0
-print("tiles", len(st), "busy", int(busy.sum()), "kernel span us %.1f" % end.max())
-print("empty tiles: start median %.1f max %.1f ; dur median %.2f p99 %.2f max %.2f" % (
-    np.median(start[~busy]), start[~busy].max(), np.median(dur[~busy]), np.percentile(dur[~busy], 99), dur[~busy].max()))
+print("tiles", len(st), "busy", int(busy.sum()), "busy span us %.1f" % end[busy].max())
 print("busy tiles : start median %.1f p90 %.1f max %.1f ; dur median %.1f p90 %.1f max %.1f ; end max %.1f" % (
     np.median(start[busy]), np.percentile(start[busy], 90), start[busy].max(), np.median(dur[busy]),
     np.percentile(dur[busy], 90), dur[busy].max(), end[busy].max()))
-order = np.argsort(-dur)[:12]
+order = np.argsort(-np.where(busy, dur, 0))[:12]
 for i in order:
     print("  tile %4d n=%3d start %.1f dur %.1f hw %x" % (i, n[i], start[i], dur[i], st[i, 3]))
 # correlation of duration with bin size
@@ -34,6 +32,16 @@ for lo, hi in [(1, 5), (5, 10), (10, 20), (20, 40), (40, 1000)]:
         print("  bin %3d..%3d: %4d tiles, dur mean %.1f max %.1f | stage %.1f cover %.1f shade+store %.1f" % (
             lo, hi, m.sum(), dur[m].mean(), dur[m].max(), stage[m].mean(), cover[m].mean(), shade[m].mean()))
 # concurrency: busy tiles resident at time t
-for t in (5, 10, 20, 40, 60, 80, 100, 120, 140):
-    print("  t=%3d us: busy resident %4d, empty resident %4d" % (t, int(((start <= t) & (end > t) & busy).sum()), int(((start <= t) & (end > t) & ~busy).sum())))
+for t in range(2, 60, 3):
+    print("  t=%3d us: busy resident %4d  started %4d finished %4d" % (
+        t, int(((start <= t) & (end > t) & busy).sum()), int(((start <= t) & busy).sum()), int(((end <= t) & busy).sum())))
+# per compute unit: when did its last busy tile end, how many did it run
+cu = st[:, 3]
+ends = {}
+for c in np.unique(cu[busy]):
+    m = busy & (cu == c)
+    ends[c] = (end[m].max(), int(m.sum()), float(dur[m].sum()))
+e = np.array([v[0] for v in ends.values()]); k = np.array([v[1] for v in ends.values()]); w = np.array([v[2] for v in ends.values()])
+print("CUs with busy tiles %d: last end min %.1f median %.1f max %.1f ; tiles per CU min %d median %d max %d ; sum of durations per CU median %.0f max %.0f" % (
+    len(e), e.min(), np.median(e), e.max(), k.min(), np.median(k), k.max(), np.median(w), w.max()))
 np.save("gpurun_out/stamps_%d_%s.npy" % (size, pipe), st)

@@ -35,6 +35,10 @@ constexpr int NBY = TILE_H / 8;  // block rows per quadrant
 constexpr int QPIX = QUAD * TILE_H;
 constexpr uint32_t NO_WINNER = 0xFFFFFFFFu;
 static_assert(NBY == 2 && TILE_H % 4 == 0, "the pixel-pair code assumes two block rows per quadrant");
+static_assert(TILE_WAVES == 4 || TILE_WAVES == 8, "a wave covers a 32 or 16 pixel wide column of the tile");
+constexpr int WAVES_PER_STRIP = TILE_WAVES / (TILE_W / STRIP);  // shading: waves sharing a 32-pixel strip
+constexpr int STRIP_ROWS = TILE_H / WAVES_PER_STRIP;            // rows of the strip each of them shades
+static_assert(STRIP_ROWS % 4 == 0, "a shading step covers four rows");
 
 __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int32_t ty)
 {
@@ -201,9 +205,10 @@ __device__ __forceinline__ uint32_t scatter_tile(uint32_t b, uint32_t n, uint32_
 
 // LDS index of pixel (qx, qy) of a quadrant: block-major, so that during coverage lane l of a
 // wave touches slot (block*64 + l): conflict-free 8-byte accesses.
-__device__ __forceinline__ uint32_t key_slot(uint32_t qx, uint32_t qy)
+__device__ __forceinline__ uint32_t key_slot(uint32_t tx, uint32_t qy)
 {
-    return (((qy >> 3) * NBX + (qx >> 3)) << 6) + ((qy & 7u) << 3) + (qx & 7u);
+    const uint32_t qx = tx % (uint32_t)QUAD;
+    return (tx / (uint32_t)QUAD) * (uint32_t)QPIX + (((qy >> 3) * NBX + (qx >> 3)) << 6) + ((qy & 7u) << 3) + (qx & 7u);
 }
 
 // Streams the cleared value of a tile (scene.rs:128-137 folded into the render): z / shadow =
@@ -217,7 +222,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
     if (a.aligned16) {
         const uint4 zmin = make_uint4(TR_F32_MIN_BITS, TR_F32_MIN_BITS, TR_F32_MIN_BITS, TR_F32_MIN_BITS);
         // depth: TILE_H rows x 32 pieces of 16 B
-        for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u; c += 256u) {
+        for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u; c += (uint32_t)TILE_THREADS) {
             const int32_t y = tile_y0 + (int32_t)(c >> 5), x = tile_x0 + (int32_t)(c & 31u) * 4;
             if (x < W && y >= a.frame.band_y0 && y < a.frame.band_y1)
                 *reinterpret_cast<uint4 *>(depth + (size_t)y * W + x) = zmin;
@@ -225,7 +230,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
         if (!DEPTH) {
             const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
             // colour: TILE_H rows x 24 pieces of 16 B
-            for (uint32_t c = tid; c < (uint32_t)TILE_H * 24u; c += 256u) {
+            for (uint32_t c = tid; c < (uint32_t)TILE_H * 24u; c += (uint32_t)TILE_THREADS) {
                 const int32_t y = tile_y0 + (int32_t)(c / 24u);
                 const int32_t xb = tile_x0 * 3 + (int32_t)(c % 24u) * 16;
                 if (xb < W * 3 && y >= a.frame.band_y0 && y < a.frame.band_y1)
@@ -233,7 +238,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
             }
             if (a.winner) {
                 const uint4 none = make_uint4(NO_WINNER, NO_WINNER, NO_WINNER, NO_WINNER);
-                for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u; c += 256u) {
+                for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u; c += (uint32_t)TILE_THREADS) {
                     const int32_t y = tile_y0 + (int32_t)(c >> 5), x = tile_x0 + (int32_t)(c & 31u) * 4;
                     if (x < W && y >= a.frame.band_y0 && y < a.frame.band_y1)
                         *reinterpret_cast<uint4 *>(a.winner + (size_t)y * W + x) = none;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
             }
         }
     } else {
-        for (uint32_t p = tid; p < (uint32_t)(TILE_W * TILE_H); p += 256u) {
+        for (uint32_t p = tid; p < (uint32_t)(TILE_W * TILE_H); p += (uint32_t)TILE_THREADS) {
             const int32_t y = tile_y0 + (int32_t)(p / TILE_W), x = tile_x0 + (int32_t)(p % TILE_W);
             if (x < W && y >= a.frame.band_y0 && y < a.frame.band_y1) {
                 depth[(size_t)y * W + x] = bits_f32(TR_F32_MIN_BITS);
@@ -263,7 +268,7 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 }
 
 template <int FS>
-__global__ __launch_bounds__(256) void k_tile(TileArgs a)
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS == FS_DARBOUX ? 4 : 6, FS == FS_DARBOUX ? 4 : 6))) void k_tile(TileArgs a)
 {
     constexpr bool DEPTH = (FS == FS_DEPTH);
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
     const int32_t tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
     const int32_t W = (int32_t)a.frame.width, H = (int32_t)a.frame.height;
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    // the wave index is uniform: say so, so that quadrant bounds and the block loop stay scalar
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
 
     // Diagnostic builds of a scene (TR_OPT_TILE_STAMPS) record when each busy tile ran; the stamps
     // go to a buffer of their own and nothing is computed from them.
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     for (uint32_t c0 = 0; c0 < n; c0 += NMAX) {
         const uint32_t m = min((uint32_t)NMAX, n - c0);
         if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
-        for (uint32_t q = tid; q < m * P; q += 256u) s_rec[q] = bin[(size_t)c0 * P + q];
+        for (uint32_t q = tid; q < m * P; q += (uint32_t)TILE_THREADS) s_rec[q] = bin[(size_t)c0 * P + q];
         __syncthreads();
         if (a.stamps && c0 == 0u) t_staged = wall_clock64();
 
@@ -383,8 +389,44 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 lcz = -lcz;
                 lry = -lry;
             }
-            const bool touch = imax((int32_t)r0.x, qx0) <= imin((int32_t)r0.y, qx0 + QUAD - 1) &&
-                               imax((int32_t)r0.z, qy0) <= imin((int32_t)r0.w, qy0 + TILE_H - 1);
+            // Which 8x8 blocks of this wave's quadrant (4 columns x 2 rows; bit i + 4 j) can hold a
+            // fragment of polygon l?  Its clamped box must meet the block, and the block must not lie
+            // wholly outside one of the three edges: cross.x, cross.y and cross.z - (cross.x + cross.y)
+            // are linear in the pixel, so their largest value over a block is the value at its origin
+            // plus 7 (|d/dx|+ + |d/dy|+).  A block is dropped only when that maximum misses zero by more
+            // than a bound on the f32 rounding of both this estimate and the per-pixel evaluation, so no
+            // pixel the exact test accepts is lost (the estimate may use fused operations: it decides
+            // nothing else).  Polygons without a live block are never visited, dead column pairs of
+            // the others are skipped: 134 K -> about 70 K block pairs at diablo 4096^2.
+            uint32_t lmask = 0u;
+            {
+                const float ox = (float)isub((int32_t)r1.x, qx0), oy = (float)isub((int32_t)r1.y, qy0);
+                const float e0x = lb1, e0y = -la1, e1x = -lb0, e1y = la0;
+                const float e2x = lb0 - lb1, e2y = la1 - la0;
+                const float e0 = la1 * oy - ox * lb1, e1 = ox * lb0 - la0 * oy;
+                const float e2 = lcz - (e0 + e1);
+                const float margin = 4.76837158e-7f /* 2^-21 */ *
+                                     (((fabsf(la1) + fabsf(la0)) * (fabsf(oy) + 16.0f) +
+                                       (fabsf(lb1) + fabsf(lb0)) * (fabsf(ox) + 32.0f)) + lcz);
+                const float m0 = e0 + (7.0f * (fmaxf(e0x, 0.0f) + fmaxf(e0y, 0.0f)) + margin);
+                const float m1 = e1 + (7.0f * (fmaxf(e1x, 0.0f) + fmaxf(e1y, 0.0f)) + margin);
+                const float m2 = e2 + (7.0f * (fmaxf(e2x, 0.0f) + fmaxf(e2y, 0.0f)) + 2.0f * margin);
+#pragma unroll
+                for (int j = 0; j < NBY; j++) {
+                    const bool rows = (int32_t)r0.z <= qy0 + 8 * j + 7 && (int32_t)r0.w >= qy0 + 8 * j;
+                    const float n0 = __builtin_fmaf(8.0f * j, e0y, m0), n1 = __builtin_fmaf(8.0f * j, e1y, m1);
+                    const float n2 = __builtin_fmaf(8.0f * j, e2y, m2);
+#pragma unroll
+                    for (int i = 0; i < NBX; i++) {
+                        const bool cols = (int32_t)r0.x <= qx0 + 8 * i + 7 && (int32_t)r0.y >= qx0 + 8 * i;
+                        const bool alive = rows && cols && __builtin_fmaf(8.0f * i, e0x, n0) >= 0.0f &&
+                                           __builtin_fmaf(8.0f * i, e1x, n1) >= 0.0f &&
+                                           __builtin_fmaf(8.0f * i, e2x, n2) >= 0.0f;
+                        lmask |= alive ? 1u << (i + NBX * j) : 0u;
+                    }
+                }
+            }
+            const bool touch = lmask != 0u;
             unsigned long long todo = __ballot(touch);
             while (todo) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(todo);
@@ -396,6 +438,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 const float z2 = __int_as_float(bcast(r3.x, l));
                 const uint32_t id = (uint32_t)bcast(r3.y, l);
                 const uint32_t slot1 = c0 + j0 + l + 1u;
+                const uint32_t live_blocks = (uint32_t)bcast(lmask, l);
                 Edge2 e;
                 e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
                 e.a1 = splat2(__int_as_float(bcast(__float_as_uint(la1), l)));
@@ -410,6 +453,7 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
                 const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
                 const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
                 for (int32_t ib = ib0; ib <= ib1; ib++) {
+                    if (!((live_blocks >> ib) & (1u | 1u << NBX))) continue;
                     // the two pixels' current keys, requested before the arithmetic that decides
                     // whether they are needed (LDS latency hidden inside the wave)
                     uint2 *slot_a = wkey + ((ib << 6) + (int32_t)lane), *slot_b = slot_a + (NBX << 6);
@@ -465,186 +509,165 @@ __global__ __launch_bounds__(256) void k_tile(TileArgs a)
     // packed to dwords with two lane permutes; the vertical flip of get_frame_buffer
     // (scene.rs:92-97) is folded into the colour address.  Lanes without a survivor run the same
     // loads on record 0 and discard the result, so the code is branch-free inside a step.
+    // Addresses are a per-wave base (scalar registers) plus a 32-bit lane offset built with 24-bit
+    // multiplies: 64-bit and 32 x 32 multiplies run at quarter rate and were a third of this
+    // phase's vector-ALU time.
+    if (TILE_WAVES != TILE_W / STRIP) __syncthreads();  // a strip spans several waves' columns
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
-    const int32_t px = qx0 + hx;
-    constexpr int NSTEP = TILE_H / 4;
-    // For the plain texture pipelines (default, phong) the NSTEP steps run as two passes: first
-    // every step's record gathers, barycentrics and texel fetches are issued, then every step is
-    // blended and stored, so the texel latency is exposed once per wave instead of once per
-    // step.  The heavier closures keep one pass per step (their registers would not fit).
-    constexpr bool TWO_PASS = (FS == FS_DEFAULT || FS == FS_PHONG);
+    const int32_t strip_x = (int32_t)(wave / (uint32_t)WAVES_PER_STRIP) * STRIP;  // within the tile
+    const int32_t strip_y = (int32_t)(wave % (uint32_t)WAVES_PER_STRIP) * STRIP_ROWS;
+    const int32_t sx0 = tile_x0 + strip_x, sy0 = qy0 + strip_y;
+    const int32_t px = sx0 + hx;
+    constexpr int NSTEP = STRIP_ROWS / 4;
+    // strip origins: depth/winner at row sy0, colour at the strip's last row (lowest address of
+    // the flipped image), so every lane offset is non-negative.  Rows outside the frame or the
+    // band give addresses that are formed but never used.
+    float *const depth_strip = depth + ((int64_t)sy0 * W + sx0);
+    uint32_t *const winner_strip = a.winner ? a.winner + ((int64_t)sy0 * W + sx0) : nullptr;
+    uint8_t *const fb_strip = DEPTH ? nullptr : a.fb + ((int64_t)(H - sy0 - STRIP_ROWS) * W + sx0) * 3;
+    const uint32_t Wu = (uint32_t)W, W3 = 3u * (uint32_t)W;
+    const bool col_live = px < W;
 
-    struct StepState {
-        int32_t py[2];
+#pragma unroll 1
+    for (int32_t sstep = 0; sstep < NSTEP; sstep++) {
+        int32_t row[2], py[2];
         bool live[2], won[2];
-        uint32_t tri[2], rgb[2], texel[2];
-        float zout[2];
-        f2 t;
-    };
-
-    // Pass 1 of a step: survivors, their records, barycentrics, depth, uv, colour (or, for the
-    // two-pass pipelines, the texel fetch and the diffuse coefficient).
-    auto shade_front = [&](int32_t sstep, StepState &st) {
         uint32_t wslot[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int32_t qy = sstep * 4 + u * 2 + hrow;
-            st.py[u] = qy0 + qy;
-            st.live[u] = px < W && st.py[u] >= a.frame.band_y0 && st.py[u] < a.frame.band_y1;
-            const uint32_t s1 = wkey[key_slot((uint32_t)hx, (uint32_t)qy)].y;
-            st.won[u] = st.live[u] && s1 != 0u;
-            wslot[u] = st.won[u] ? s1 - 1u : 0u;
-            st.tri[u] = NO_WINNER;
-            st.rgb[u] = 0u;
-            st.texel[u] = 0u;
-            st.zout[u] = bits_f32(TR_F32_MIN_BITS);
+            row[u] = sstep * 4 + u * 2 + hrow;  // within the strip
+            py[u] = sy0 + row[u];
+            live[u] = col_live && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+            const uint32_t s1 = s_key[key_slot((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
+            won[u] = live[u] && s1 != 0u;
+            wslot[u] = won[u] ? s1 - 1u : 0u;
         }
-        st.t = splat2(0.0f);
-        if (!__any(st.won[0] || st.won[1])) return;
-        uint4 qa[P], qb[P];
-        if (resident) {
+        uint32_t tri[2] = { NO_WINNER, NO_WINNER }, rgb[2] = { 0u, 0u };
+        float zout[2] = { bits_f32(TR_F32_MIN_BITS), bits_f32(TR_F32_MIN_BITS) };
+        if (__any(won[0] || won[1])) {
+            uint4 qa[P], qb[P];
+            if (resident) {
+                const uint4 *ra = s_rec + mul24(wslot[0], (uint32_t)P), *rb = s_rec + mul24(wslot[1], (uint32_t)P);
 #pragma unroll
-            for (int i = 1; i < P; i++) {
-                qa[i] = s_rec[wslot[0] * P + i];
-                qb[i] = s_rec[wslot[1] * P + i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 1; i < P; i++) {
-                qa[i] = bin[(size_t)wslot[0] * P + i];
-                qb[i] = bin[(size_t)wslot[1] * P + i];
-            }
-        }
-        // to_barycentric_coord for both pixels (each against its own polygon)
-        Edge2 e;
-        e.a0 = mk2((float)isub((int32_t)qa[1].z, (int32_t)qa[1].x), (float)isub((int32_t)qb[1].z, (int32_t)qb[1].x));
-        e.a1 = mk2((float)isub((int32_t)qa[2].x, (int32_t)qa[1].x), (float)isub((int32_t)qb[2].x, (int32_t)qb[1].x));
-        e.b0 = mk2((float)isub((int32_t)qa[1].w, (int32_t)qa[1].y), (float)isub((int32_t)qb[1].w, (int32_t)qb[1].y));
-        e.b1 = mk2((float)isub((int32_t)qa[2].y, (int32_t)qa[1].y), (float)isub((int32_t)qb[2].y, (int32_t)qb[1].y));
-        e.cz = e.a0 * e.b1 - e.a1 * e.b0;
-        e.y = mk2(__uint_as_float(qa[P - 1].w), __uint_as_float(qb[P - 1].w));
-        const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));
-        const f2 b2 = mk2((float)isub((int32_t)qa[1].y, st.py[0]), (float)isub((int32_t)qb[1].y, st.py[1]));
-        f2 cx, cy;
-        edge_cross2(e, a2, b2, cx, cy);
-        const Bary2 bar = barycentric2(cx, cy, e);
-        const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
-                            mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
-                            mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
-        uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
-        if (!DEPTH) {
-            // uv = vertex_uvs * bar (2x3 gemv), both pixels
-            f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
-            f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
-            uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
-            vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
-            uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
-            vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
-            if (TWO_PASS) {
-                // shader.rs:318-333 / 386-401: texel now, color_blend in the second pass
-                st.texel[0] = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
-                st.texel[1] = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
-                const f2 i0 = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
-                st.t = i0;
-                if (FS == FS_PHONG)
-                    st.t = dot3_2(bar.x, bar.y, bar.z, i0, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
-                                  mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
-            } else {
-                float va[VARY_STRIDE], vb[VARY_STRIDE];
-                va[0] = __uint_as_float(qa[3].z); va[1] = __uint_as_float(qa[3].w);
-                vb[0] = __uint_as_float(qb[3].z); vb[1] = __uint_as_float(qb[3].w);
-#pragma unroll
-                for (int i = 4; i < P; i++) {
-                    va[4 * i - 14] = __uint_as_float(qa[i].x); va[4 * i - 13] = __uint_as_float(qa[i].y);
-                    va[4 * i - 12] = __uint_as_float(qa[i].z); va[4 * i - 11] = __uint_as_float(qa[i].w);
-                    vb[4 * i - 14] = __uint_as_float(qb[i].x); vb[4 * i - 13] = __uint_as_float(qb[i].y);
-                    vb[4 * i - 12] = __uint_as_float(qb[i].z); vb[4 * i - 11] = __uint_as_float(qb[i].w);
+                for (int i = 1; i < P; i++) {
+                    qa[i] = ra[i];
+                    qb[i] = rb[i];
                 }
-                ca = fragment_color<FS>(a.u, a.tex, va, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, (uint32_t)px,
-                                        (uint32_t)st.py[0], z.x, a.shadow, (uint32_t)W, (uint32_t)H, ea);
-                cb = fragment_color<FS>(a.u, a.tex, vb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, (uint32_t)px,
-                                        (uint32_t)st.py[1], z.y, a.shadow, (uint32_t)W, (uint32_t)H, eb);
-            }
-        }
-        uint32_t err = 0u;
-        if (st.won[0]) {
-            st.zout[0] = z.x;
-            st.rgb[0] = ca;
-            st.tri[0] = qa[3].y;
-            err |= ea;
-        }
-        if (st.won[1]) {
-            st.zout[1] = z.y;
-            st.rgb[1] = cb;
-            st.tri[1] = qb[3].y;
-            err |= eb;
-        }
-        if (err) atomicOr(a.err, err);
-    };
-
-    // Pass 2 of a step: color_blend for the two-pass pipelines, then the stores.
-    auto shade_back = [&](StepState &st) {
-        if (TWO_PASS) {
-            const f2 k = (splat2(1.0f) - st.t) * splat2(0.0f);  // (1 - t) * color_2, color_2 = 0
-            uint32_t ca = 0u, cb = 0u;
+            } else {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const f2 v = st.t * mk2((float)((st.texel[0] >> (8 * ch)) & 0xFFu),
-                                        (float)((st.texel[1] >> (8 * ch)) & 0xFFu)) + k;
-                ca |= f32_to_u8(v.x) << (8 * ch);
-                cb |= f32_to_u8(v.y) << (8 * ch);
+                for (int i = 1; i < P; i++) {
+                    qa[i] = bin[(size_t)wslot[0] * P + i];
+                    qb[i] = bin[(size_t)wslot[1] * P + i];
+                }
             }
-            if (st.won[0]) st.rgb[0] = ca;
-            if (st.won[1]) st.rgb[1] = cb;
+            // to_barycentric_coord for both pixels (each against its own polygon)
+            Edge2 e;
+            e.a0 = mk2((float)isub((int32_t)qa[1].z, (int32_t)qa[1].x), (float)isub((int32_t)qb[1].z, (int32_t)qb[1].x));
+            e.a1 = mk2((float)isub((int32_t)qa[2].x, (int32_t)qa[1].x), (float)isub((int32_t)qb[2].x, (int32_t)qb[1].x));
+            e.b0 = mk2((float)isub((int32_t)qa[1].w, (int32_t)qa[1].y), (float)isub((int32_t)qb[1].w, (int32_t)qb[1].y));
+            e.b1 = mk2((float)isub((int32_t)qa[2].y, (int32_t)qa[1].y), (float)isub((int32_t)qb[2].y, (int32_t)qb[1].y));
+            e.cz = e.a0 * e.b1 - e.a1 * e.b0;
+            e.y = mk2(__uint_as_float(qa[P - 1].w), __uint_as_float(qb[P - 1].w));
+            const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));
+            const f2 b2 = mk2((float)isub((int32_t)qa[1].y, py[0]), (float)isub((int32_t)qb[1].y, py[1]));
+            f2 cx, cy;
+            edge_cross2(e, a2, b2, cx, cy);
+            const Bary2 bar = barycentric2(cx, cy, e);
+            const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
+                                mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
+                                mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
+            uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
+            if (!DEPTH) {
+                // uv = vertex_uvs * bar (2x3 gemv), both pixels
+                f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
+                f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
+                uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
+                vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
+                uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
+                vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
+                if (FS == FS_DEFAULT || FS == FS_PHONG) {
+                    // shader.rs:318-333 / 386-401 for both pixels at once: texel, diffuse term,
+                    // color_blend(c, 0, t) = (t * c + (1 - t) * 0.0) as u8 per channel
+                    const uint32_t ta = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
+                    const uint32_t tb = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
+                    f2 t = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
+                    if (FS == FS_PHONG)
+                        t = dot3_2(bar.x, bar.y, bar.z, t, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
+                                   mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
+                    const f2 k = (splat2(1.0f) - t) * splat2(0.0f);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+                        ca |= f32_to_u8(v.x) << (8 * ch);
+                        cb |= f32_to_u8(v.y) << (8 * ch);
+                    }
+                } else {
+                    float va[VARY_STRIDE], vb[VARY_STRIDE];
+                    va[0] = __uint_as_float(qa[3].z); va[1] = __uint_as_float(qa[3].w);
+                    vb[0] = __uint_as_float(qb[3].z); vb[1] = __uint_as_float(qb[3].w);
+#pragma unroll
+                    for (int i = 4; i < P; i++) {
+                        va[4 * i - 14] = __uint_as_float(qa[i].x); va[4 * i - 13] = __uint_as_float(qa[i].y);
+                        va[4 * i - 12] = __uint_as_float(qa[i].z); va[4 * i - 11] = __uint_as_float(qa[i].w);
+                        vb[4 * i - 14] = __uint_as_float(qb[i].x); vb[4 * i - 13] = __uint_as_float(qb[i].y);
+                        vb[4 * i - 12] = __uint_as_float(qb[i].z); vb[4 * i - 11] = __uint_as_float(qb[i].w);
+                    }
+                    ca = fragment_color<FS>(a.u, a.tex, va, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, (uint32_t)px,
+                                            (uint32_t)py[0], z.x, a.shadow, (uint32_t)W, (uint32_t)H, ea);
+                    cb = fragment_color<FS>(a.u, a.tex, vb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, (uint32_t)px,
+                                            (uint32_t)py[1], z.y, a.shadow, (uint32_t)W, (uint32_t)H, eb);
+                }
+            }
+            uint32_t err = 0u;
+            if (won[0]) {
+                zout[0] = z.x;
+                rgb[0] = ca;
+                tri[0] = qa[3].y;
+                err |= ea;
+            }
+            if (won[1]) {
+                zout[1] = z.y;
+                rgb[1] = cb;
+                tri[1] = qb[3].y;
+                err |= eb;
+            }
+            if (err) atomicOr(a.err, err);
         }
+
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            if (!DEPTH && !a.fresh && st.live[u] && !st.won[u]) {
+            const uint32_t zoff = mul24((uint32_t)row[u], Wu) + (uint32_t)hx;
+            const uint32_t coff = mul24((uint32_t)(STRIP_ROWS - 1 - row[u]), W3);  // the row's first byte
+            if (!DEPTH && !a.fresh && live[u] && !won[u]) {
                 // untouched pixel of an accumulate render: its colour may share a dword with a
                 // touched neighbour, so fetch it
-                const uint8_t *old = a.fb + ((size_t)(H - 1 - st.py[u]) * W + px) * 3;
-                st.rgb[u] = pack_rgb(old[0], old[1], old[2]);
+                const uint8_t *old = fb_strip + (coff + 3u * (uint32_t)hx);
+                rgb[u] = pack_rgb(old[0], old[1], old[2]);
             }
             // depth: only pixels that changed (or every live pixel of a fresh tile)
-            const bool put = st.live[u] && (st.won[u] || a.fresh);
-            if (put) depth[(size_t)st.py[u] * W + px] = st.zout[u];
+            const bool put = live[u] && (won[u] || a.fresh);
+            if (put) depth_strip[zoff] = zout[u];
             if (!DEPTH) {
-                if (a.winner && put) a.winner[(size_t)st.py[u] * W + px] = st.tri[u];
-                uint8_t *row = a.fb + ((size_t)(H - 1 - st.py[u]) * W + qx0) * 3;
+                if (winner_strip && put) winner_strip[zoff] = tri[u];
                 if (a.aligned4) {
                     // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
                     // on, topped up from pixel p0+1
                     const uint32_t j = (uint32_t)hx;
                     const uint32_t p0 = (4u * j) / 3u, o = (4u * j) % 3u;
-                    const uint32_t c0 = (uint32_t)__shfl((int)st.rgb[u], (int)(half_base + (p0 & 31u)), 64);
-                    const uint32_t c1 = (uint32_t)__shfl((int)st.rgb[u], (int)(half_base + ((p0 + 1u) & 31u)), 64);
+                    const uint32_t c0 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + (p0 & 31u)), 64);
+                    const uint32_t c1 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + ((p0 + 1u) & 31u)), 64);
                     const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
-                    const bool row_live = st.py[u] >= a.frame.band_y0 && st.py[u] < a.frame.band_y1;
-                    if (j < 24u && row_live && (qx0 * 3 + (int32_t)(4u * j)) < W * 3)
-                        *reinterpret_cast<uint32_t *>(row + 4u * j) = dw;
+                    const bool row_live = py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+                    if (j < 24u && row_live && (sx0 * 3 + (int32_t)(4u * j)) < W * 3)
+                        *reinterpret_cast<uint32_t *>(fb_strip + (coff + 4u * j)) = dw;
                 } else if (put) {
-                    uint8_t *p = row + 3 * hx;
-                    p[0] = (uint8_t)(st.rgb[u] & 0xFFu);
-                    p[1] = (uint8_t)((st.rgb[u] >> 8) & 0xFFu);
-                    p[2] = (uint8_t)((st.rgb[u] >> 16) & 0xFFu);
+                    uint8_t *p = fb_strip + (coff + 3u * (uint32_t)hx);
+                    p[0] = (uint8_t)(rgb[u] & 0xFFu);
+                    p[1] = (uint8_t)((rgb[u] >> 8) & 0xFFu);
+                    p[2] = (uint8_t)((rgb[u] >> 16) & 0xFFu);
                 }
             }
-        }
-    };
-
-    if (TWO_PASS) {
-        StepState st[NSTEP];
-#pragma unroll
-        for (int sstep = 0; sstep < NSTEP; sstep++) shade_front(sstep, st[sstep]);
-#pragma unroll
-        for (int sstep = 0; sstep < NSTEP; sstep++) shade_back(st[sstep]);
-    } else {
-#pragma unroll 1
-        for (int32_t sstep = 0; sstep < NSTEP; sstep++) {
-            StepState st;
-            shade_front(sstep, st);
-            shade_back(st);
         }
     }
 
@@ -739,7 +762,7 @@ int launch_tile(int fs, const TileArgs &a, hipStream_t st, hipEvent_t start, hip
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
-    const dim3 grid(3u * n_tiles), block(256);
+    const dim3 grid(3u * n_tiles), block(TILE_THREADS);
     switch (fs) {
     case FS_DEFAULT: hipExtLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, start, done, 0, a); break;
     case FS_PHONG: hipExtLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, start, done, 0, a); break;

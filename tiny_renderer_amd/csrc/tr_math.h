@@ -130,6 +130,17 @@ TR_HD uint32_t f32_to_u8(float v)
 }
 #endif
 
+// a * b for operands below 2^24 (texture and frame dimensions, record slots): one full-rate
+// instruction on the device, where a 32 x 32 bit multiply takes four.
+TR_HD uint32_t mul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+
 // Correctly rounded x / d for many numerators and one divisor.  y = RN(1/d) comes from one IEEE
 // division; q0 = RN(x*y) is corrected twice with exact FMA residuals (Markstein: with
 // y = RN(1/d) and q faithful, RN(q + (x - d*q)*y) = RN(x/d); the first correction makes q

@@ -287,7 +287,7 @@ TR_HD uint32_t fetch_texel(const DevTextures &tex, int which, int dims, float u,
         cx = cx >= tex.w[which] ? tex.w[which] - 1u : cx;
         cy = cy >= tex.h[which] ? tex.h[which] - 1u : cy;
     }
-    return tex.texel[which][(size_t)cy * tex.w[which] + cx];
+    return tex.texel[which][mul24(cy, tex.w[which]) + cx];  // dimensions are at most 2^14 (checked at create)
 }
 
 // util.rs:51-56

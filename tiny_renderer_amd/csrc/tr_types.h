@@ -49,7 +49,16 @@ constexpr int TILE_W = 128;
 #define TR_TILE_H 16
 #endif
 constexpr int TILE_H = TR_TILE_H;
-constexpr int QUAD = 32;
+// Wavefronts per tile workgroup.  Each owns a TILE_W / TILE_WAVES pixel wide column of the tile
+// during coverage; for shading the tile is re-divided into 32-pixel wide strips so that every
+// row a wave stores is whole cache lines.
+#ifndef TR_TILE_WAVES
+#define TR_TILE_WAVES 4
+#endif
+constexpr int TILE_WAVES = TR_TILE_WAVES;
+constexpr int TILE_THREADS = 64 * TILE_WAVES;
+constexpr int QUAD = TILE_W / TILE_WAVES;
+constexpr int STRIP = 32;
 
 // Raster part of a polygon record (64 B).  Mirrors Buffer.vertex_t_raster / vertex_z_values
 // (shader.rs:34-35) plus the clamped bounding box of scene.rs:233-239.  bx0 > bx1 marks a
