@@ -450,49 +450,60 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
                 // this lane's two pixels: (px, pya) in block row 0 and (px, pyb) in block row 1
                 const int32_t pya = qy0 + ly, pyb = qy0 + 8 + ly;
                 const f2 b2 = mk2((float)isub(y0, pya), (float)isub(y0, pyb));
+                // the inside test (scene.rs:245-247 on to_barycentric_coord's cross products, divided
+                // by cross.z > 0): cross.x >= 0, cross.y >= 0, cross.x + cross.y <= cross.z.  The last is
+                // taken as cross.z - (cross.x + cross.y) >= 0 (same truth value: a difference of two
+                // floats has the sign of the exact difference) so that one three-way minimum and one
+                // compare decide a pixel; a row outside the clamped box gets -inf for cross.z.
                 const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
+                const f2 czp = mk2(rowa ? cz : -__builtin_inff(), rowb ? cz : -__builtin_inff());
                 const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
-                for (int32_t ib = ib0; ib <= ib1; ib++) {
-                    if (!((live_blocks >> ib) & (1u | 1u << NBX))) continue;
+                // column pairs inside the box with a live block
+                uint32_t cols = (live_blocks | (live_blocks >> NBX)) & ((2u << ib1) - (1u << ib0));
+                while (cols) {
+                    const int32_t ib = (int32_t)__builtin_ctz(cols);
+                    cols &= cols - 1u;
                     // the two pixels' current keys, requested before the arithmetic that decides
                     // whether they are needed (LDS latency hidden inside the wave)
                     uint2 *slot_a = wkey + ((ib << 6) + (int32_t)lane), *slot_b = slot_a + (NBX << 6);
                     const uint2 cur_a = *slot_a, cur_b = *slot_b;
                     const int32_t px = qx0 + ib * 8 + lx;
-                    const bool inx = px >= bx0 && px <= bx1;
+                    const bool inx = (uint32_t)isub(px, bx0) <= (uint32_t)isub(bx1, bx0);
                     f2 cx, cy;
                     edge_cross2(e, splat2((float)isub(x0, px)), b2, cx, cy);
-                    const f2 sum = cx + cy;
-                    const bool hita = inx && rowa && cx.x >= 0.0f && cy.x >= 0.0f && sum.x <= cz;
-                    const bool hitb = inx && rowb && cx.y >= 0.0f && cy.y >= 0.0f && sum.y <= cz;
+                    const f2 rest = czp - (cx + cy);
+                    const bool hita = inx && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
+                    const bool hitb = inx && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
                     if (hita || hitb) {
                         // depth of both fragments; only compared here (the survivor's stored z is
                         // recomputed with exact zero signs when it is shaded)
                         const Bary2 bar = barycentric2_for_compare(cx, cy, e);
                         const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
+                        // both comparisons first, branch-free, so that the two key reads above are
+                        // consumed together after the arithmetic; equal depths (shared vertices and
+                        // edges, or the buffer's previous content) are the rare divergent path
+                        const float zca = __uint_as_float(cur_a.x), zcb = __uint_as_float(cur_b.x);
+                        bool wina = hita && z.x > zca, winb = hitb && z.y > zcb;
+                        const bool tiea = hita && z.x == zca, tieb = hitb && z.y == zcb;
+                        if (tiea || tieb) {
+                            // equal depth: the buffer's previous content beats a colour fragment
+                            // (`z <= zbuf` rejects) and loses to a depth fragment (`z >= shadow`
+                            // accepts); between two fragments of this pass the polygon index decides
 #pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            if (!(h == 0 ? hita : hitb)) continue;
-                            const float zf = h == 0 ? z.x : z.y;
-                            uint2 *slot = h == 0 ? slot_a : slot_b;
-                            const uint2 cur = h == 0 ? cur_a : cur_b;
-                            const float zc = __uint_as_float(cur.x);
-                            bool win = zf > zc;
-                            if (zf == zc) {
-                                // equal depth: the buffer's previous content beats a colour
-                                // fragment (`z <= zbuf` rejects) and loses to a depth fragment
-                                // (`z >= shadow` accepts); between two fragments of this pass
-                                // the polygon index decides
-                                if (cur.y == 0u) {
-                                    win = DEPTH;
-                                } else {
-                                    const uint32_t cur_id = resident ? s_rec[(cur.y - 1u) * P + 3].y
-                                                                     : bin[(size_t)(cur.y - 1u) * P + 3].y;
-                                    win = DEPTH ? id > cur_id : id < cur_id;
+                            for (int h = 0; h < 2; h++) {
+                                if (!(h == 0 ? tiea : tieb)) continue;
+                                const uint32_t cs = h == 0 ? cur_a.y : cur_b.y;
+                                bool w = DEPTH;
+                                if (cs != 0u) {
+                                    const uint32_t cur_id = resident ? s_rec[(cs - 1u) * P + 3].y
+                                                                     : bin[(size_t)(cs - 1u) * P + 3].y;
+                                    w = DEPTH ? id > cur_id : id < cur_id;
                                 }
+                                if (h == 0) wina = w; else winb = w;
                             }
-                            if (win) *slot = make_uint2(__float_as_uint(zf), slot1);
                         }
+                        if (wina) *slot_a = make_uint2(__float_as_uint(z.x), slot1);
+                        if (winb) *slot_b = make_uint2(__float_as_uint(z.y), slot1);
                     }
                 }
             }

@@ -255,19 +255,40 @@ struct Bary2 {
 // depth comparison of the coverage loop, not for values that are stored.
 TR_HD Bary2 barycentric2_for_compare(f2 cx, f2 cy, const Edge2 &e)
 {
+    // the three quotients of div_by2_unsigned_zero advanced in lockstep: each step's three
+    // operations are independent, so no dependent packed operation issues back to back
+    const f2 s = cx + cy;
+    const f2 q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
+    f2 es = fma2(-q0s, e.cz, s), ex = fma2(-q0x, e.cz, cx), ey = fma2(-q0y, e.cz, cy);
+    f2 qs = fma2(es, e.y, q0s), qx = fma2(ex, e.y, q0x), qy = fma2(ey, e.y, q0y);
+    es = fma2(-qs, e.cz, s);
+    ex = fma2(-qx, e.cz, cx);
+    ey = fma2(-qy, e.cz, cy);
     Bary2 b;
-    b.x = splat2(1.0f) - div_by2_unsigned_zero(cx + cy, e.cz, e.y);
-    b.y = div_by2_unsigned_zero(cx, e.cz, e.y);
-    b.z = div_by2_unsigned_zero(cy, e.cz, e.y);
+    b.x = splat2(1.0f) - fma2(es, e.y, qs);
+    b.y = fma2(ex, e.y, qx);
+    b.z = fma2(ey, e.y, qy);
     return b;
 }
 
 TR_HD Bary2 barycentric2(f2 cx, f2 cy, const Edge2 &e)
 {
+    // div_by2 for the three numerators in lockstep (see barycentric2_for_compare), here with the
+    // sign of a zero quotient kept: these values are stored and shaded
+    const f2 s = cx + cy;
+    const f2 q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
+    f2 es = fma2(-q0s, e.cz, s), ex = fma2(-q0x, e.cz, cx), ey = fma2(-q0y, e.cz, cy);
+    f2 qs = fma2(es, e.y, q0s), qx = fma2(ex, e.y, q0x), qy = fma2(ey, e.y, q0y);
+    es = fma2(-qs, e.cz, s);
+    ex = fma2(-qx, e.cz, cx);
+    ey = fma2(-qy, e.cz, cy);
+    qs = fma2(es, e.y, qs);
+    qx = fma2(ex, e.y, qx);
+    qy = fma2(ey, e.y, qy);
     Bary2 b;
-    b.x = splat2(1.0f) - div_by2(cx + cy, e.cz, e.y);
-    b.y = div_by2(cx, e.cz, e.y);
-    b.z = div_by2(cy, e.cz, e.y);
+    b.x = splat2(1.0f) - mk2(s.x == 0.0f ? q0s.x : qs.x, s.y == 0.0f ? q0s.y : qs.y);
+    b.y = mk2(cx.x == 0.0f ? q0x.x : qx.x, cx.y == 0.0f ? q0x.y : qx.y);
+    b.z = mk2(cy.x == 0.0f ? q0y.x : qy.x, cy.y == 0.0f ? q0y.y : qy.y);
     return b;
 }
 
@@ -287,7 +308,7 @@ TR_HD uint32_t fetch_texel(const DevTextures &tex, int which, int dims, float u,
         cx = cx >= tex.w[which] ? tex.w[which] - 1u : cx;
         cy = cy >= tex.h[which] ? tex.h[which] - 1u : cy;
     }
-    return tex.texel[which][mul24(cy, tex.w[which]) + cx];  // dimensions are at most 2^14 (checked at create)
+    return tex.texel[which][mul24(cy, tex.w[which]) + cx];  // sides are below 2^16 (checked at create)
 }
 
 // util.rs:51-56
