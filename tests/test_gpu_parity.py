@@ -101,6 +101,49 @@ def test_render_twice_without_clear_accumulates(small_synthetic, pipe):
     assert_parity(gpu, cpu, pipe)
 
 
+@pytest.mark.parametrize("peek", [False, True])
+@pytest.mark.parametrize("band", [None, (100, 420)])
+def test_fast_depth_clear(small_synthetic, peek, band):
+    """Empty tiles of a cleared frame keep their z behind a per-tile flag instead of in memory.  An
+    accumulating render that lands on such tiles, a clear that is read before any render, and the
+    z getters (with the flags still up, or already lowered by an earlier read) must all see f32::MIN."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 1024, 512
+    kw = {"band_rows": band} if band else {}
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", winner_tap=True, **kw)
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    rows = slice(*band) if band else slice(None)  # output rows (row 0 = top) this scene owns
+    zrows = slice(Hh - band[1], Hh - band[0]) if band else slice(None)  # z rows count from the bottom
+
+    def check():
+        zo = cpu.z_f32().view(np.uint32).reshape(Hh, W)[zrows]
+        zg = gpu.read_z_f32().view(np.uint32).reshape(Hh, W)[zrows]
+        assert np.array_equal(zg, zo)
+        assert np.array_equal(gpu.get_frame_buffer()[rows], cpu.get_frame_buffer()[rows])
+        assert np.array_equal(gpu.get_z_buffer()[rows], cpu.get_z_buffer()[rows])
+
+    views = [([0.0, 0.0, 1.0], [0.0, 0.0, 0.0]), ([0.9, 0.3, 1.0], [0.9, 0.3, 0.0]), ([-0.8, -0.4, 1.0], [-0.8, -0.4, 0.0])]
+    for s in (gpu, cpu):
+        s.clear()
+        s.set_light_direction(H.light(0.3))
+    for k, (frm, at) in enumerate(views):  # three renders without a clear, each on other tiles
+        for s in (gpu, cpu):
+            s.set_camera(frm, at, [0.0, 1.0, 0.0])
+            s.render()
+        if peek or k == len(views) - 1:
+            check()
+    for s in (gpu, cpu):  # a clear read back before any render, then a render on top of it
+        s.clear()
+    if peek:
+        check()
+    for s in (gpu, cpu):
+        s.set_camera(views[1][0], views[1][1], [0.0, 1.0, 0.0])
+        s.render()
+    check()
+
+
 def test_initial_state_and_clear_only(small_synthetic):
     """Buffer::new zero-fills (shader.rs:46-47); clear sets f32::MIN / 0 (scene.rs:128-137)."""
     import tiny_renderer_amd as T

@@ -214,7 +214,8 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t tx, uint32_t qy)
 // Streams the cleared value of a tile (scene.rs:128-137 folded into the render): z / shadow =
 // f32::MIN, rgb = 0.  Whole-tile rows are whole cache lines; 16 B per lane when width % 16 == 0.
 template <bool DEPTH>
-__device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t tile_x0, int32_t tile_y0)
+__device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t tile_x0, int32_t tile_y0,
+                                                   bool with_depth)
 {
     const int32_t W = (int32_t)a.frame.width, H = (int32_t)a.frame.height;
     const uint32_t tid = threadIdx.x;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
     if (a.aligned16) {
         const uint4 zmin = make_uint4(TR_F32_MIN_BITS, TR_F32_MIN_BITS, TR_F32_MIN_BITS, TR_F32_MIN_BITS);
         // depth: TILE_H rows x 32 pieces of 16 B
-        for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u; c += (uint32_t)TILE_THREADS) {
+        for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u && with_depth; c += (uint32_t)TILE_THREADS) {
             const int32_t y = tile_y0 + (int32_t)(c >> 5), x = tile_x0 + (int32_t)(c & 31u) * 4;
             if (x < W && y >= a.frame.band_y0 && y < a.frame.band_y1)
                 *reinterpret_cast<uint4 *>(depth + (size_t)y * W + x) = zmin;
@@ -249,7 +250,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
         for (uint32_t p = tid; p < (uint32_t)(TILE_W * TILE_H); p += (uint32_t)TILE_THREADS) {
             const int32_t y = tile_y0 + (int32_t)(p / TILE_W), x = tile_x0 + (int32_t)(p % TILE_W);
             if (x < W && y >= a.frame.band_y0 && y < a.frame.band_y1) {
-                depth[(size_t)y * W + x] = bits_f32(TR_F32_MIN_BITS);
+                if (with_depth) depth[(size_t)y * W + x] = bits_f32(TR_F32_MIN_BITS);
                 if (!DEPTH) {
                     uint8_t *px = a.fb + ((size_t)(H - 1 - y) * W + x) * 3;
                     px[0] = 0;
@@ -308,9 +309,13 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
                 a.busy_n_next[1] = 0u;
             }
         }
-        if (a.tile_count[t] == 0u && a.fresh)
+        if (a.tile_count[t] == 0u && a.fresh) {
+            // an empty tile of a cleared frame: its colour is zeros; its z stays unwritten behind
+            // the tile's fast-clear flag (depth passes write their f32::MIN)
             write_cleared_tile<DEPTH>(a, (int32_t)(t % a.frame.ntx) * TILE_W,
-                                      (a.frame.ty_base + (int32_t)(t / a.frame.ntx)) * TILE_H);
+                                      (a.frame.ty_base + (int32_t)(t / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
+            if (tid == 0u && a.zclean) a.zclean[t] = 1u;
+        }
         return;
     }
     const bool heavy_part = blockIdx.x < n_heavy;
@@ -331,6 +336,9 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
     if (a.stamps) t_start = wall_clock64();
 
     float *depth = DEPTH ? a.shadow : a.zbuf;
+    // is every z of this tile logically f32::MIN (cleared frame, or fast-clear flag still set)?
+    // then nothing is read and every live z is written, after which the flag is down
+    const bool zfresh = a.fresh || (a.zclean && a.zclean[tile] != 0u);
     const int32_t qx0 = tile_x0 + (int32_t)wave * QUAD, qy0 = tile_y0;
     uint2 *wkey = s_key + wave * QPIX;
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
 #pragma unroll
         for (int b = 0; b < NBX * NBY; b++) {
             uint32_t zb = TR_F32_MIN_BITS;
-            if (!a.fresh) {
+            if (!zfresh) {
                 const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
                 if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
                     zb = __float_as_uint(depth[(size_t)py * W + px]);
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
                 rgb[u] = pack_rgb(old[0], old[1], old[2]);
             }
             // depth: only pixels that changed (or every live pixel of a fresh tile)
-            const bool put = live[u] && (won[u] || a.fresh);
+            const bool put = live[u] && (won[u] || zfresh);
             if (put) depth_strip[zoff] = zout[u];
             if (!DEPTH) {
                 if (winner_strip && put) winner_strip[zoff] = tri[u];
@@ -682,6 +690,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
         }
     }
 
+    if (a.zclean && tid == 0u) a.zclean[tile] = 0u;
+
     if (a.stamps) {
         __syncthreads();
         if (tid == 0u) {
@@ -698,6 +708,22 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
 // -----------------------------------------------------------------------------------------
 // Small utility kernels
 // -----------------------------------------------------------------------------------------
+
+// Writes the f32::MIN of every colour-pass tile whose fast-clear flag is up and lowers the flag:
+// run before anything reads the z buffer as plain memory (tr_scene_read_z_f32, get_z_buffer).
+__global__ __launch_bounds__(256) void k_materialize_depth(float *zbuf, uint32_t *zclean, DevFrame frame)
+{
+    const uint32_t t = blockIdx.x;
+    if (zclean[t] == 0u) return;
+    const int32_t x0 = (int32_t)(t % frame.ntx) * TILE_W, y0 = (frame.ty_base + (int32_t)(t / frame.ntx)) * TILE_H;
+    for (uint32_t p = threadIdx.x; p < (uint32_t)(TILE_W * TILE_H); p += 256u) {
+        const int32_t y = y0 + (int32_t)(p / TILE_W), x = x0 + (int32_t)(p % TILE_W);
+        if (x < (int32_t)frame.width && y >= frame.band_y0 && y < frame.band_y1)
+            zbuf[(size_t)y * frame.width + x] = bits_f32(TR_F32_MIN_BITS);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) zclean[t] = 0u;
+}
 
 // Scene::clear materialised (scene.rs:128-137) for the cases the render cannot fold it in.
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *dst, uint32_t value, size_t n)
@@ -795,6 +821,15 @@ int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st)
     size_t blocks = (n + 255u) / 256u;
     if (blocks > 8192u) blocks = 8192u;
     hipLaunchKernelGGL(k_fill_u32, dim3((uint32_t)blocks), dim3(256), 0, st, dst, value, n);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st)
+{
+    const uint32_t n_tiles = frame.ntx * frame.nty;
+    if (n_tiles == 0) return 0;
+    hipLaunchKernelGGL(k_materialize_depth, dim3(n_tiles), dim3(256), 0, st, zbuf, zclean, frame);
     TR_LAUNCH_CHECK();
     return 0;
 }

@@ -135,6 +135,10 @@ struct tr_scene {
     bool own_fb = false;
     uint8_t *d_view = nullptr;  // scratch for get_z_buffer / get_shadow_buffer
     uint32_t *d_winner = nullptr;
+    // Fast depth clear: one word per colour-pass tile, non-zero = "every z of the tile is f32::MIN,
+    // memory not written".  Raised by the tile kernel for the empty tiles of a cleared frame (and by
+    // a clear that has to be materialised), lowered by whoever writes the tile's z.
+    uint32_t *d_zclean = nullptr;
     uint64_t *d_stamps = nullptr;
     uint32_t *d_err = nullptr;
 
@@ -242,8 +246,8 @@ int flush_clear_color(tr_scene *s)
     const size_t z_first = W * (size_t)s->frame.band_y0;
     const size_t fb_first = W * (size_t)(s->height - (uint32_t)s->frame.band_y1) * 3;
     Timed t(s, K_CLEAR);
-    int rc = launch_fill_u32(reinterpret_cast<uint32_t *>(s->d_z) + z_first, TR_F32_MIN_BITS, n, s->stream);
-    if (rc) return launch_status(rc, "clear z");
+    // z: raise every tile's fast-clear flag; colour (and the winner tap) are real memory
+    HIP_TRY(hipMemsetAsync(s->d_zclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_fb + fb_first, 0, n * 3, s->stream));
     if (s->d_winner) HIP_TRY(hipMemsetAsync(s->d_winner + z_first, 0xFF, n * 4, s->stream));
     s->z_fb_cleared = false;
@@ -258,6 +262,14 @@ int flush_clear_shadow(tr_scene *s)
     int rc = launch_fill_u32(reinterpret_cast<uint32_t *>(s->d_shadow), TR_F32_MIN_BITS, n, s->stream);
     if (rc) return launch_status(rc, "clear shadow");
     s->shadow_cleared = false;
+    return TR_OK;
+}
+
+// Gives the z buffer plain-memory meaning: tiles still behind their fast-clear flag get their f32::MIN.
+int materialize_depth(tr_scene *s)
+{
+    int rc = launch_materialize_depth(s->d_z, s->d_zclean, s->frame, s->stream);
+    if (rc) return launch_status(rc, "k_materialize_depth");
     return TR_OK;
 }
 
@@ -427,6 +439,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.shadow = s->d_shadow;
     ta.fb = s->d_fb;
     ta.winner = s->d_winner;
+    ta.zclean = depth_pass ? nullptr : s->d_zclean;
     ta.err = s->d_err;
     ta.fresh = fresh;
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
@@ -506,6 +519,7 @@ void destroy(tr_scene *s)
     if (s->own_fb) dev_free(s->d_fb);
     dev_free(s->d_view);
     dev_free(s->d_winner);
+    dev_free(s->d_zclean);
     dev_free(s->d_stamps);
     dev_free(s->d_err);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -634,6 +648,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if ((st = dev_alloc(&s->d_shadow, npx))) return st;
     HIP_TRY(hipMemset(s->d_z, 0, npx * 4));
     HIP_TRY(hipMemset(s->d_shadow, 0, npx * 4));
+    if ((st = dev_alloc(&s->d_zclean, (size_t)s->n_tiles))) return st;
+    HIP_TRY(hipMemset(s->d_zclean, 0, (size_t)s->n_tiles * 4));
     if (o.frame_buffer_device) {
         s->d_fb = (uint8_t *)o.frame_buffer_device;
     } else {
@@ -818,6 +834,7 @@ int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb)
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
     int st = flush_clear_color(s);
+    if (st == TR_OK) st = materialize_depth(s);
     if (st != TR_OK) return st;
     return depth_view(s, s->d_z, rgb);
 }
@@ -836,6 +853,7 @@ int tr_scene_read_z_f32(tr_scene *s, float *out)
     if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
     int st = flush_clear_color(s);
+    if (st == TR_OK) st = materialize_depth(s);
     if (st != TR_OK) return st;
     return read_back(s, out, s->d_z, (size_t)s->width * s->height * 4);
 }

@@ -202,7 +202,10 @@ struct TileArgs {
     uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
     uint32_t scatter_bits; // block b renders tile scatter(b): a bijective hash on [0, n_tiles) built on
                            // [0, 2^scatter_bits) by cycle walking
-    uint64_t *stamps;   // diagnostic only (TR_OPT_TILE_STAMPS): per tile {start, end, polygons, hw id}; else nullptr
+    uint64_t *stamps;
+    // Fast depth clear: zclean[t] != 0 says every z of colour-pass tile t is logically f32::MIN and
+    // its memory is stale (null for depth passes, whose shadow buffer is looked up at random).
+    uint32_t *zclean;   // diagnostic only (TR_OPT_TILE_STAMPS): per tile {start, end, polygons, hw id}; else nullptr
 };
 
 }  // namespace tr
