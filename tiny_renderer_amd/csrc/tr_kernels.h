@@ -13,6 +13,9 @@ namespace tr {
 // signalled by the kernel's completion without a separate event packet, and the pair brackets
 // exactly the kernel's execution when both are timing events.
 int launch_setup(int vs_kind, const SetupArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done);
+// Builds the tile kernel's work list from the counters k_setup filled (same stream, after it).
+int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkItem *order, uint32_t n_tiles, hipStream_t st, hipEvent_t start,
+                 hipEvent_t done);
 int launch_tile(int fs_kind, const TileArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done);
 int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
     // A wave takes only SETUP_POLYS polygons (the other lanes idle through the short vertex
     // stage) but all 64 lanes share the binning below: the polygons of one wave can span hundreds
     // of tiles, and the wave with the most (polygon, tile) pairs is the kernel's critical path.
+
     const uint32_t lane = threadIdx.x;
     const uint32_t t = blockIdx.x * SETUP_POLYS + lane;
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
     constexpr int PAIRS = 8;  // pairs per lane per trip: their atomics are in flight together
     for (int32_t p0 = (int32_t)lane; p0 < total; p0 += 64 * PAIRS) {
         int32_t own[PAIRS], tile[PAIRS];
-        uint32_t slot[PAIRS], pos[PAIRS];
+        uint32_t slot[PAIRS];
 #pragma unroll
         for (int k = 0; k < PAIRS; k++) {
             const int32_t p = p0 + 64 * k;
@@ -143,31 +144,6 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
         for (int k = 0; k < PAIRS; k++)
             slot[k] = own[k] >= 0 ? atomicAdd(&a.tile_count[tile[k]], 1u) : 0u;
 
-        // First record of a tile: put the tile on the busy list, which k_tile runs first.  Every
-        // lane of every wave shares ONE list counter (a single word takes ~90 atomics per
-        // microsecond), so the wave reserves a range with one atomic per trip and its lanes take
-        // consecutive entries.
-        // ... and likewise on the heavy list when its HEAVY_AT-th record arrives.
-#pragma unroll
-        for (int which = 0; which < 2; which++) {
-            const uint32_t at = which == 0 ? 0u : HEAVY_AT - 1u;
-            uint32_t *list = which == 0 ? a.busy_list : a.heavy_list;
-            uint32_t firsts = 0u;
-#pragma unroll
-            for (int k = 0; k < PAIRS; k++) {
-                const unsigned long long mask = __ballot(own[k] >= 0 && slot[k] == at);
-                pos[k] = firsts + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                firsts += (uint32_t)__builtin_popcountll(mask);
-            }
-            if (firsts) {
-                uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(a.busy_n + which, firsts);
-                base = (uint32_t)__shfl((int)base, 0, 64);
-#pragma unroll
-                for (int k = 0; k < PAIRS; k++)
-                    if (own[k] >= 0 && slot[k] == at) list[base + pos[k]] = (uint32_t)tile[k];
-            }
-        }
 #pragma unroll
         for (int k = 0; k < PAIRS; k++) {
             if (own[k] < 0) continue;
@@ -185,8 +161,24 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
 }
 
 // -----------------------------------------------------------------------------------------
-// k_tile
+// k_order_count, k_order_place
 // -----------------------------------------------------------------------------------------
+// Turn the per-tile polygon counts k_setup left into the tile kernel's work list: every tile once,
+// as (tile, count), bucketed by count -- >= 64, >= 32, ... , 1, and the empty tiles last.  With
+// the list the tile kernel needs one scalar load to know its tile and size (it used to chase list
+// length -> list entry -> counter), is launched with exactly one workgroup per tile, and packs by
+// eight weight classes (longest-processing-time first).
+// Two small kernels, one thread per tile: the first counts the buckets, the second gives every
+// tile its position.  A wave counts its members of a bucket with a ballot and issues one atomic
+// per bucket.  (A single workgroup doing both sweeps took 16-40 us: it shares one compute unit
+// with six resident waves per SIMD of the previous pass's tile kernel.)  Both run on the setup
+// stream beside that tile kernel.  The 16 words they use follow the tile counters (words
+// n_tiles .. n_tiles + 15: bucket sizes, then cursors) and rotate and get zeroed with them.
+// Inside a bucket the tiles come in a hashed order: consecutive workgroups are dealt round-robin
+// to the XCDs and their compute units, and tiles that are neighbours on the screen cost about the
+// same and read the same texture region -- in row-major order the tile kernel was 15 % slower.
+constexpr int ORDER_BUCKETS = 8;
+constexpr int ORDER_THREADS = 256;
 
 // Bijection on [0, n): odd multiplications and xor-shifts are bijections on [0, 2^bits); values
 // that fall outside [0, n) are walked through the same map again (cycle walking).
@@ -202,6 +194,66 @@ __device__ __forceinline__ uint32_t scatter_tile(uint32_t b, uint32_t n, uint32_
     } while (x >= n);
     return x;
 }
+
+__device__ __forceinline__ uint32_t order_bucket(uint32_t n)
+{
+    if (n == 0u) return ORDER_BUCKETS - 1;
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(n);  // floor(log2 n)
+    return lg >= (uint32_t)(ORDER_BUCKETS - 2) ? 0u : (uint32_t)(ORDER_BUCKETS - 2) - lg;
+}
+
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_count(uint32_t *tile_count, uint32_t n_tiles, uint32_t bits)
+{
+    const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool live = i < n_tiles;
+    const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
+    const uint32_t bk = order_bucket(live ? tile_count[t] : 0u);
+    // lane b ends up with the wave's size of bucket b; the eight lanes add in one instruction
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int b = 0; b < ORDER_BUCKETS; b++) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(live && bk == (uint32_t)b));
+        if (lane == (uint32_t)b) mine = c;
+    }
+    if (lane < (uint32_t)ORDER_BUCKETS && mine) atomicAdd(&tile_count[n_tiles + lane], mine);
+}
+
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_place(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles,
+                                                                uint32_t bits)
+{
+    const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const bool live = i < n_tiles;
+    const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
+    const uint32_t n = live ? tile_count[t] : 0u;
+    const uint32_t bk = order_bucket(n);
+    // lane b reserves the wave's range in bucket b (one atomic instruction, one round trip for all
+    // eight) and knows where the bucket starts; members then take base + rank
+    uint32_t mine = 0u, rank = 0u;
+#pragma unroll
+    for (int b = 0; b < ORDER_BUCKETS; b++) {
+        const unsigned long long m = __ballot(live && bk == (uint32_t)b);
+        if (lane == (uint32_t)b) mine = (uint32_t)__builtin_popcountll(m);
+        if (bk == (uint32_t)b) rank = (uint32_t)__builtin_popcountll(m & below);
+    }
+    uint32_t base = 0u;
+    if (lane < (uint32_t)ORDER_BUCKETS) {
+        const uint32_t *sizes = tile_count + n_tiles;
+        for (uint32_t b = 0; b < lane; b++) base += sizes[b];
+        if (mine) base += atomicAdd(&tile_count[n_tiles + ORDER_BUCKETS + lane], mine);
+    }
+    const uint32_t pos = (uint32_t)__shfl((int)base, (int)bk, 64) + rank;
+    if (live) {
+        WorkItem w;
+        w.tile = t;
+        w.count = n;
+        order[pos] = w;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// k_tile
+// -----------------------------------------------------------------------------------------
 
 // LDS index of pixel (qx, qy) of a quadrant: block-major, so that during coverage lane l of a
 // wave touches slot (block*64 + l): conflict-free 8-byte accesses.
@@ -281,47 +333,30 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
     __shared__ uint2 s_key[TILE_W * TILE_H];
     __shared__ uint4 s_rec[NMAX * P];
 
-    // The launch has 3 * n_tiles blocks (heavy list + busy list + sweep, each at most n_tiles).
-    //   * The first blocks run the lists k_setup built of tiles with at least one polygon: the
-    //     long, VALU-bound ones, heaviest (>= HEAVY_AT polygons) first.  They come first so that
-    //     the machine is full of them from the first microsecond (a row-major walk meets the last
-    //     busy tile at its very end) and the longest ones do not form the tail.
-    //   * The next n_tiles blocks are the "sweep": every tile is visited once in a hashed
-    //     order (neighbouring tiles scattered over the launch); the sweep streams the cleared
-    //     value of the empty tiles -- short, HBM-bound work -- and zeroes the ping-pong counters
-    //     for the next pass.
-    // Measured alternatives (profiles/r01_notes.md): interleaving the two kinds, or letting the
-    // busy blocks issue the sweep stores themselves, was 5-10 % slower.  Any order is correct.
-    const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
+    // One workgroup per tile, in the order k_order laid out: tiles with polygons first -- the long,
+    // VALU-bound ones, heaviest first (longest-processing-time-first packing, and the machine is
+    // full of them from the first microsecond) -- then the empty tiles, whose workgroups only
+    // stream the cleared colour of a fresh frame: short, HBM-bound work that fills the slots the
+    // busy tiles free.  Measured alternatives (profiles/r01_notes.md): interleaving the two kinds,
+    // or letting the busy blocks issue those stores themselves, was 5-10 % slower.  Any order is
+    // correct.  Every workgroup also zeroes its tile's counter for a later pass.
     const uint32_t tid = threadIdx.x;
-    // busy part: heavy tiles (>= HEAVY_AT polygons) first, then the remaining busy tiles; the
-    // sweep follows immediately; workgroups past n_heavy + n_light + n_tiles have nothing to do
-    // (the launch is sized for the worst case, 3 n_tiles)
-    const uint32_t n_light = a.busy_n[0], n_heavy = a.busy_n[1];
-    if (blockIdx.x >= n_heavy + n_light) {
-        const uint32_t i = blockIdx.x - (n_heavy + n_light);
-        if (i >= n_tiles) return;
-        const uint32_t t = scatter_tile(i, n_tiles, a.scatter_bits);
-        if (tid == 0u) {
-            a.tile_count_next[t] = 0u;
-            if (i == 0u) {
-                a.busy_n_next[0] = 0u;
-                a.busy_n_next[1] = 0u;
-            }
-        }
-        if (a.tile_count[t] == 0u && a.fresh) {
+    const WorkItem work = a.order[blockIdx.x];
+    const uint32_t tile = work.tile;
+    uint32_t n = work.count;
+    if (tid == 0u) a.tile_count_next[tile] = 0u;
+    if (blockIdx.x == 0u && tid < 2u * (uint32_t)ORDER_BUCKETS)
+        a.tile_count_next[a.frame.ntx * a.frame.nty + tid] = 0u;  // k_order's bucket sizes and cursors
+    if (n == 0u) {
+        if (a.fresh) {
             // an empty tile of a cleared frame: its colour is zeros; its z stays unwritten behind
             // the tile's fast-clear flag (depth passes write their f32::MIN)
-            write_cleared_tile<DEPTH>(a, (int32_t)(t % a.frame.ntx) * TILE_W,
-                                      (a.frame.ty_base + (int32_t)(t / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
-            if (tid == 0u && a.zclean) a.zclean[t] = 1u;
+            write_cleared_tile<DEPTH>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
+                                      (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
+            if (tid == 0u && a.zclean) a.zclean[tile] = 1u;
         }
         return;
     }
-    const bool heavy_part = blockIdx.x < n_heavy;
-    const uint32_t tile = heavy_part ? a.heavy_list[blockIdx.x] : a.busy_list[blockIdx.x - n_heavy];
-    uint32_t n = a.tile_count[tile];
-    if (!heavy_part && n >= HEAVY_AT) return;  // rendered by its heavy-list workgroup
     if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
@@ -794,12 +829,26 @@ int launch_setup(int vs, const SetupArgs &a, hipStream_t st, hipEvent_t start, h
     return 0;
 }
 
+int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, hipStream_t st, hipEvent_t start,
+                 hipEvent_t done)
+{
+    if (n_tiles == 0) return 0;
+    const dim3 grid((n_tiles + ORDER_THREADS - 1u) / ORDER_THREADS), block(ORDER_THREADS);
+    uint32_t bits = 1;
+    while ((1u << bits) < n_tiles) bits++;
+    hipExtLaunchKernelGGL(k_order_count, grid, block, 0, st, start, nullptr, 0, tile_count, n_tiles, bits);
+    TR_LAUNCH_CHECK();
+    hipExtLaunchKernelGGL(k_order_place, grid, block, 0, st, nullptr, done, 0, tile_count, order, n_tiles, bits);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_tile(int fs, const TileArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
-    const dim3 grid(3u * n_tiles), block(TILE_THREADS);
+    const dim3 grid(n_tiles), block(TILE_THREADS);
     switch (fs) {
     case FS_DEFAULT: hipExtLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, start, done, 0, a); break;
     case FS_PHONG: hipExtLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, start, done, 0, a); break;

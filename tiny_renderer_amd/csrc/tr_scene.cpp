@@ -69,8 +69,8 @@ const PipelineDesc kPipelines[P_COUNT] = {
     { "occlusion", 2, { { 1, VS_DEPTH, FS_DEPTH }, { 2, VS_PLAIN, FS_OCCLUSION2 } } },
 };
 
-const char *kKernelNames[] = { "k_setup", "k_tile", "k_tile_depth", "k_clear" };
-enum KernelId { K_SETUP = 0, K_TILE, K_TILE_DEPTH, K_CLEAR, K_COUNT };
+const char *kKernelNames[] = { "k_setup", "k_tile", "k_tile_depth", "k_clear", "k_order" };
+enum KernelId { K_SETUP = 0, K_TILE, K_TILE_DEPTH, K_CLEAR, K_ORDER, K_COUNT };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -111,13 +111,11 @@ struct tr_scene {
     // setup kernel of pass q + 1 (running beside it on the setup stream) fills set (q + 1) % 3.
     struct BinState {
         uint32_t *count[3] = { nullptr, nullptr, nullptr };
-        uint32_t *list[3] = { nullptr, nullptr, nullptr };
-        uint32_t *heavy[3] = { nullptr, nullptr, nullptr };
-        uint32_t *nbusy = nullptr;  // two words (busy, heavy) per set
         uint64_t seq = 0;           // passes of this kind issued so far
     } bin_color, bin_depth;
     // Record bins, double buffered by global pass number: pass p's setup fills bins[p % 2] while
     // pass p - 1's tile kernel is still reading bins[(p - 1) % 2].
+    WorkItem *d_order[2] = { nullptr, nullptr };  // the tile kernel's work list (k_order), buffered like the bins
     Piece *d_bins[2] = { nullptr, nullptr };  // each n_tiles_full x bin_cap records of rec_pieces x 16 B
     // Pass pipelining: k_setup of pass p runs on `setup_stream`, ordered after the tile kernel of
     // pass p - 2 (which frees its bins and zeroed its counters) and before the tile kernel of pass p
@@ -399,9 +397,6 @@ int run_pass(tr_scene *s, const PassDesc &p)
     const uint64_t p_seq = s->pass_seq;
     Piece *bins = s->d_bins[p_seq % 2];
     sa.tile_count = bs.count[set_cur];
-    sa.busy_list = bs.list[set_cur];
-    sa.heavy_list = bs.heavy[set_cur];
-    sa.busy_n = bs.nbusy + 2 * set_cur;
     sa.bins = bins;
     sa.bin_cap = s->bin_cap;
     sa.rec_pieces = s->rec_pieces;
@@ -409,15 +404,23 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.err = s->d_err;
     // setup on its own stream: after the tile kernel of pass p - 2, before the tile kernel of pass p
     if (p_seq >= 2) HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - 2) % 4], 0));
+    const uint32_t n_tiles_pass = frame.ntx * frame.nty;
     if (!s->profiling) {
-        int rc = launch_setup(p.vs, sa, s->setup_stream, nullptr, s->ev_setup[p_seq % 4]);
+        int rc = launch_setup(p.vs, sa, s->setup_stream, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % 2], n_tiles_pass, s->setup_stream, nullptr,
+                          s->ev_setup[p_seq % 4]);
+        if (rc) return launch_status(rc, "k_order");
     } else {
-        // profiling: timing events on the dispatch itself, then the pipeline's event separately
+        // profiling: timing events on the dispatches themselves, then the pipeline's event separately
         EventPair ep = { take_event(s), take_event(s), K_SETUP };
         int rc = launch_setup(p.vs, sa, s->setup_stream, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
-        s->events.push_back(ep);
+        if (s->mesh.n_tri) s->events.push_back(ep);
+        EventPair eo = { take_event(s), take_event(s), K_ORDER };
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % 2], n_tiles_pass, s->setup_stream, eo.a, eo.b);
+        if (rc) return launch_status(rc, "k_order");
+        s->events.push_back(eo);
         HIP_TRY(hipEventRecord(s->ev_setup[p_seq % 4], s->setup_stream));
     }
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[p_seq % 4], 0));
@@ -426,12 +429,8 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.bins = bins;
     ta.bin_cap = s->bin_cap;
     ta.rec_pieces = s->rec_pieces;
-    ta.tile_count = bs.count[set_cur];
-    ta.busy_list = bs.list[set_cur];
-    ta.heavy_list = bs.heavy[set_cur];
-    ta.busy_n = bs.nbusy + 2 * set_cur;
+    ta.order = s->d_order[p_seq % 2];
     ta.tile_count_next = bs.count[set_zero];
-    ta.busy_n_next = bs.nbusy + 2 * set_zero;
     ta.frame = frame;
     ta.u = du;
     ta.tex = s->tex;
@@ -445,8 +444,6 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
-    ta.scatter_bits = 1;
-    while ((1u << ta.scatter_bits) < frame.ntx * frame.nty) ta.scatter_bits++;
     if (!s->profiling) {
         int rc = launch_tile(p.fs, ta, s->stream, nullptr, s->ev_tile[p_seq % 4]);
         if (rc) return launch_status(rc, "k_tile");
@@ -506,11 +503,10 @@ void destroy(tr_scene *s)
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
         for (int k = 0; k < 3; k++) {
             dev_free(b->count[k]);
-            dev_free(b->list[k]);
-            dev_free(b->heavy[k]);
         }
-        dev_free(b->nbusy);
     }
+    dev_free(s->d_order[0]);
+    dev_free(s->d_order[1]);
     dev_free(s->d_bins[0]);
     dev_free(s->d_bins[1]);
     dev_free(s->d_bin_need);
@@ -620,14 +616,13 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
         const size_t nt = (b == &s->bin_color) ? s->n_tiles : s->n_tiles_full;
         for (int k = 0; k < 3; k++) {
-            if ((st = dev_alloc(&b->count[k], nt))) return st;
-            if ((st = dev_alloc(&b->list[k], nt))) return st;
-            if ((st = dev_alloc(&b->heavy[k], nt))) return st;
-            HIP_TRY(hipMemset(b->count[k], 0, nt * 4));
+            // nt counters, then k_order's 8 bucket sizes and 8 cursors
+            if ((st = dev_alloc(&b->count[k], nt + 16))) return st;
+            HIP_TRY(hipMemset(b->count[k], 0, (nt + 16) * 4));
         }
-        if ((st = dev_alloc(&b->nbusy, 6))) return st;
-        HIP_TRY(hipMemset(b->nbusy, 0, 24));
     }
+    for (int k = 0; k < 2; k++)
+        if ((st = dev_alloc(&s->d_order[k], (size_t)s->n_tiles_full))) return st;
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
     uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
     if (cap > mesh->n_tri) cap = mesh->n_tri;               // a bin never holds more than all polygons

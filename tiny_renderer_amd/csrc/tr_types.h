@@ -97,7 +97,6 @@ constexpr int REC_PIECES_LARGE = 9;  // 144 B
 constexpr int LDS_REC_BYTES = 8192;
 // A tile whose bin reaches this many polygons is "heavy": the tile kernel starts heavy tiles
 // first (longest-processing-time-first packing of the launch).
-constexpr uint32_t HEAVY_AT = 12;
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {
@@ -162,14 +161,16 @@ enum DevErr : uint32_t {
 // with one atomic per (polygon, tile) pair and may run past bin_cap; entries beyond it are dropped,
 // DE_BIN_OVERFLOW is raised and bin_need records the largest count seen so the host can grow the
 // bins and render the frame again.
+// One entry of the tile kernel's work list (k_order).
+struct alignas(8) WorkItem {
+    uint32_t tile, count;
+};
+
 struct SetupArgs {
     DevMesh mesh;
     DevFrame frame;
     DevUniforms u;
     uint32_t *tile_count;
-    uint32_t *busy_list;   // tiles that received their first record, in arrival order
-    uint32_t *heavy_list;  // tiles that received their HEAVY_AT-th record: k_tile starts these first
-    uint32_t *busy_n;      // [0] length of busy_list, [1] length of heavy_list
     Piece *bins;        // n_tiles x bin_cap records of rec_pieces x 16 B
     uint32_t bin_cap;
     uint32_t rec_pieces;
@@ -181,14 +182,12 @@ struct TileArgs {
     const Piece *bins;
     uint32_t bin_cap;
     uint32_t rec_pieces;
-    // Counters ping-pong between passes of the same kind: this pass reads `tile_count` /
-    // `busy_list` / `busy_n` (filled by its k_setup) and zeroes the other set for the next pass.
-    const uint32_t *tile_count;
-    const uint32_t *busy_list;
-    const uint32_t *heavy_list;
-    const uint32_t *busy_n;  // [0] busy tiles, [1] heavy tiles
+    // The launch's work list, one entry per tile (built by k_order from this pass's counters):
+    // workgroup b renders tile order[b].x, which holds order[b].y polygons; heaviest first, the
+    // empty tiles last.  Counters rotate between passes of the same kind: each workgroup zeroes its
+    // tile's counter in the set a later pass will fill.
+    const WorkItem *order;
     uint32_t *tile_count_next;
-    uint32_t *busy_n_next;
     DevFrame frame;
     DevUniforms u;
     DevTextures tex;
@@ -200,12 +199,10 @@ struct TileArgs {
     uint32_t fresh;     // 1: target buffers are logically cleared (scene.rs:128-137 folded in)
     uint32_t aligned16; // 1: width % 16 == 0, cleared rows can be written in 16-byte pieces
     uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
-    uint32_t scatter_bits; // block b renders tile scatter(b): a bijective hash on [0, n_tiles) built on
-                           // [0, 2^scatter_bits) by cycle walking
-    uint64_t *stamps;
+    uint64_t *stamps;   // diagnostic only (TR_OPT_TILE_STAMPS): per tile {start, end, polygons, hw id}; else nullptr
     // Fast depth clear: zclean[t] != 0 says every z of colour-pass tile t is logically f32::MIN and
     // its memory is stale (null for depth passes, whose shadow buffer is looked up at random).
-    uint32_t *zclean;   // diagnostic only (TR_OPT_TILE_STAMPS): per tile {start, end, polygons, hw id}; else nullptr
+    uint32_t *zclean;
 };
 
 }  // namespace tr
