@@ -1,0 +1,33 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): collects the round's judged evidence into gpurun_out/prof/.
+#   bench line (with cpu_baseline), rocprofv3 kernel stats of the same bench command,
+#   HBM traffic counters (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, as
+#   MI355X_MICROARCH.md prescribes) and SQ instruction / cycle counters of a plain frame loop.
+# Copy what should be judged into profiles/ afterwards (scripts/summarise_profiles.py).
+set -o pipefail
+out=gpurun_out/prof
+rm -rf "$out"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+
+echo "== bench"
+python3 bench.py --steps 200 --warmup 20 > "$out/bench_4096_phong.log" 2> "$out/bench_4096_phong.err" || exit 1
+tail -n 1 "$out/bench_4096_phong.log"
+
+echo "== kernel trace"
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu \
+    > "$out/bench_under_rocprof.log" 2> "$out/trace.err" || exit 1
+tail -n 1 "$out/bench_under_rocprof.log"
+
+for c in FETCH_SIZE WRITE_SIZE; do
+  echo "== pmc $c"
+  rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$c" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 20 \
+      > "$out/pmc_$c.log" 2>&1 || exit 1
+done
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA"; do
+  n=$(echo $set | tr ' ' '_' | cut -c1-48)
+  echo "== pmc $set"
+  rocprofv3 --pmc $set --kernel-trace -d "$out/sq_$n" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 12 \
+      > "$out/sq_$n.log" 2>&1 || echo "counter set refused: $set"
+done
+find "$out" -name "*.csv" | head -40

@@ -247,7 +247,15 @@ extern "C" int tr_emul_covers(const int32_t raster[6], int32_t px, int32_t py, f
     edge_cross(e, px, py, cx, cy);
     const vec3 b = barycentric(cx, cy, e.cz);
     bar_out[0] = b.x; bar_out[1] = b.y; bar_out[2] = b.z;
-    return covers(cx, cy, e.cz) ? 1 : 0;
+    // bit 1: the tile kernel's orientation-normalised form of the same test
+    Edge n = e;
+    if (n.cz < 0.0f) {
+        n.a0 = -n.a0; n.a1 = -n.a1; n.b0 = -n.b0; n.b1 = -n.b1;
+        n.cz = -n.cz;
+    }
+    float nx, ny;
+    edge_cross(n, px, py, nx, ny);
+    return (covers(cx, cy, e.cz) ? 1 : 0) | (covers_oriented(nx, ny, n.cz) ? 2 : 0);
 }
 
 extern "C" uint32_t tr_emul_depth_order_key(float z) { return depth_order_key(z); }

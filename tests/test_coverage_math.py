@@ -1,5 +1,6 @@
 """The product's arithmetic substitutions, checked on the CPU against the dividing forms:
-  * division-free inside test (tr_shaders.h `covers`) vs the reference's sign tests on the
+  * division-free inside tests (tr_shaders.h `covers`, and `covers_oriented`: the orientation-
+    normalised three-way-minimum form of the tile kernel) vs the reference's sign tests on the
     divided barycentric coordinates (scene.rs:192-196, 245) as restated by the oracle;
   * shared-reciprocal division (tr_math.h `div_by`) vs IEEE '/';
   * depth_order_key is monotone and folds -0.0 onto +0.0."""
@@ -25,9 +26,10 @@ def _check_triangles(tris, pts):
             if got < 0:   # degenerate: the oracle reports (-1, 1, 1)
                 assert list(bo) == [-1.0, 1.0, 1.0]
                 continue
-            assert bool(got) == ref_inside, (list(t), px, py, list(bo))
+            # bit 0: `covers`; bit 1: `covers_oriented`, the form the tile kernel evaluates
+            assert (got & 1) == ref_inside and (got >> 1) == ref_inside, (list(t), px, py, list(bo), got)
             assert np.array_equal(np.array(bo, np.float32).view(np.uint32), np.array(be, np.float32).view(np.uint32))
-            n_cov += got
+            n_cov += got & 1
     return n_cov
 
 

@@ -220,6 +220,17 @@ TR_HD bool covers(float cx, float cy, float cz)
     return cx <= 0.0f && cy <= 0.0f && s >= cz;
 }
 
+// The form the tile kernel evaluates (two pixels at a time, packed): the polygon is first
+// orientation-normalised -- a0, a1, b0, b1 negated when cross.z < 0, which negates cross.x and
+// cross.y exactly -- so that cz > 0, and `s <= cz` is taken as cz - s >= 0 (a difference of two
+// floats has the sign of the exact difference; f32 denormals are on), which lets one three-way
+// minimum and one compare decide a pixel.  Checked against `covers` and the dividing form by
+// tests/test_coverage_math.py.
+TR_HD bool covers_oriented(float cx, float cy, float cz_positive)
+{
+    return fminf(fminf(cx, cy), cz_positive - (cx + cy)) >= 0.0f;
+}
+
 TR_HD vec3 barycentric(float cx, float cy, float cz)
 {
     return make3(1.0f - (cx + cy) / cz, cx / cz, cy / cz);
