@@ -76,6 +76,10 @@ typedef struct tr_options {
                                   all-gather buffer); NULL = library-owned */
     uint64_t bin_capacity;     /* polygon records per screen-tile bin; 0 = default (256); bins grow
                                   on overflow and the frame is rendered again */
+    uint32_t tile_waves;       /* wavefronts per 128x16 screen tile: 4, 8, 16, or 0 = automatic (more
+                                  while the tiles cannot fill the GPU, 4 from 4096x4096 up).
+                                  Speed only: results do not depend on it. */
+    uint32_t reserved0;
 } tr_options;
 
 typedef struct tr_scene tr_scene;

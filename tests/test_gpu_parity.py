@@ -56,6 +56,20 @@ def test_synthetic_all_pipelines(synthetic, pipe):
 
 
 @pytest.mark.parametrize("pipe", ALL)
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_tile_layouts(synthetic, pipe, waves):
+    """tr_options.tile_waves: four, eight or sixteen wavefronts per screen tile (the automatic choice
+    takes sixteen for frames this small, four from 4096^2 up); results must not depend on it."""
+    mesh, texs = synthetic
+    gpu, cpu = render_pair(801, 603, mesh, texs, pipe, -0.3, 0.9, tile_waves=waves)
+    assert_parity(gpu, cpu, pipe)
+    for s in (gpu, cpu):  # and an accumulating render on top
+        s.set_camera(*H.camera(0.8))
+        s.render()
+    assert_parity(gpu, cpu, pipe)
+
+
+@pytest.mark.parametrize("pipe", ALL)
 @pytest.mark.parametrize("angles", [(0.0, 0.0), (0.7, -1.1)])
 def test_diablo_800(diablo, pipe, angles):
     mesh, texs = diablo

@@ -30,15 +30,9 @@ namespace tr {
 
 namespace {
 
-constexpr int NBX = QUAD / 8;    // 8x8 lane blocks per quadrant row
 constexpr int NBY = TILE_H / 8;  // block rows per quadrant
-constexpr int QPIX = QUAD * TILE_H;
 constexpr uint32_t NO_WINNER = 0xFFFFFFFFu;
 static_assert(NBY == 2 && TILE_H % 4 == 0, "the pixel-pair code assumes two block rows per quadrant");
-static_assert(TILE_WAVES == 4 || TILE_WAVES == 8, "a wave covers a 32 or 16 pixel wide column of the tile");
-constexpr int WAVES_PER_STRIP = TILE_WAVES / (TILE_W / STRIP);  // shading: waves sharing a 32-pixel strip
-constexpr int STRIP_ROWS = TILE_H / WAVES_PER_STRIP;            // rows of the strip each of them shades
-static_assert(STRIP_ROWS % 4 == 0, "a shading step covers four rows");
 
 __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int32_t ty)
 {
@@ -257,15 +251,17 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_place(uint32_t *tile_co
 
 // LDS index of pixel (qx, qy) of a quadrant: block-major, so that during coverage lane l of a
 // wave touches slot (block*64 + l): conflict-free 8-byte accesses.
+template <int QUAD>
 __device__ __forceinline__ uint32_t key_slot(uint32_t tx, uint32_t qy)
 {
+    constexpr int NBX = QUAD / 8, QPIX = QUAD * TILE_H;
     const uint32_t qx = tx % (uint32_t)QUAD;
     return (tx / (uint32_t)QUAD) * (uint32_t)QPIX + (((qy >> 3) * NBX + (qx >> 3)) << 6) + ((qy & 7u) << 3) + (qx & 7u);
 }
 
 // Streams the cleared value of a tile (scene.rs:128-137 folded into the render): z / shadow =
 // f32::MIN, rgb = 0.  Whole-tile rows are whole cache lines; 16 B per lane when width % 16 == 0.
-template <bool DEPTH>
+template <bool DEPTH, int TILE_THREADS>
 __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t tile_x0, int32_t tile_y0,
                                                    bool with_depth)
 {
@@ -320,9 +316,17 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
     return __builtin_amdgcn_readlane((int)v, (int)lane);
 }
 
-template <int FS>
-__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS == FS_DARBOUX ? 4 : 6, FS == FS_DARBOUX ? 4 : 6))) void k_tile(TileArgs a)
+template <int FS, int TILE_WAVES>
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(FS == FS_DARBOUX ? 4 : 6, FS == FS_DARBOUX ? 4 : 6))) void k_tile(TileArgs a)
 {
+    static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
+    constexpr int TILE_THREADS = 64 * TILE_WAVES;
+    constexpr int QUAD = TILE_W / TILE_WAVES;  // width of a wave's column
+    constexpr int NBX = QUAD / 8;              // 8x8 lane blocks per quadrant row
+    constexpr int QPIX = QUAD * TILE_H;
+    constexpr int WAVES_PER_STRIP = TILE_WAVES / (TILE_W / STRIP);  // shading: waves sharing a 32-pixel strip
+    constexpr int STRIP_ROWS = TILE_H / WAVES_PER_STRIP;            // rows of the strip each of them shades
+    static_assert(STRIP_ROWS % 4 == 0, "a shading step covers four rows");
     constexpr bool DEPTH = (FS == FS_DEPTH);
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     constexpr int NMAX = LDS_REC_BYTES / (P * 16);  // records resident in LDS
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
         if (a.fresh) {
             // an empty tile of a cleared frame: its colour is zeros; its z stays unwritten behind
             // the tile's fast-clear flag (depth passes write their f32::MIN)
-            write_cleared_tile<DEPTH>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
+            write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
                                       (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
             if (tid == 0u && a.zclean) a.zclean[tile] = 1u;
         }
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(FS
             row[u] = sstep * 4 + u * 2 + hrow;  // within the strip
             py[u] = sy0 + row[u];
             live[u] = col_live && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
-            const uint32_t s1 = s_key[key_slot((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
+            const uint32_t s1 = s_key[key_slot<QUAD>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
             won[u] = live[u] && s1 != 0u;
             wslot[u] = won[u] ? s1 - 1u : 0u;
         }
@@ -843,25 +847,34 @@ int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, hipStr
     return 0;
 }
 
-int launch_tile(int fs, const TileArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done)
+template <int WAVES>
+static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
-    const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
-    if (n_tiles == 0) return 0;
-    if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
-    const dim3 grid(n_tiles), block(TILE_THREADS);
+    const dim3 grid(n_tiles), block(64 * WAVES);
     switch (fs) {
-    case FS_DEFAULT: hipExtLaunchKernelGGL(k_tile<FS_DEFAULT>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_PHONG: hipExtLaunchKernelGGL(k_tile<FS_PHONG>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_NORMAL_MAP: hipExtLaunchKernelGGL(k_tile<FS_NORMAL_MAP>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_SPECULAR: hipExtLaunchKernelGGL(k_tile<FS_SPECULAR>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_DARBOUX: hipExtLaunchKernelGGL(k_tile<FS_DARBOUX>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_SHADOW2: hipExtLaunchKernelGGL(k_tile<FS_SHADOW2>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_OCCLUSION2: hipExtLaunchKernelGGL(k_tile<FS_OCCLUSION2>, grid, block, 0, st, start, done, 0, a); break;
-    case FS_DEPTH: hipExtLaunchKernelGGL(k_tile<FS_DEPTH>, grid, block, 0, st, start, done, 0, a); break;
+    case FS_DEFAULT: hipExtLaunchKernelGGL((k_tile<FS_DEFAULT, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_PHONG: hipExtLaunchKernelGGL((k_tile<FS_PHONG, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_NORMAL_MAP: hipExtLaunchKernelGGL((k_tile<FS_NORMAL_MAP, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_SPECULAR: hipExtLaunchKernelGGL((k_tile<FS_SPECULAR, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_DARBOUX: hipExtLaunchKernelGGL((k_tile<FS_DARBOUX, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_SHADOW2: hipExtLaunchKernelGGL((k_tile<FS_SHADOW2, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_OCCLUSION2: hipExtLaunchKernelGGL((k_tile<FS_OCCLUSION2, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_DEPTH: hipExtLaunchKernelGGL((k_tile<FS_DEPTH, WAVES>), grid, block, 0, st, start, done, 0, a); break;
     default: return (int)hipErrorInvalidValue;
     }
     TR_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_tile(int fs, const TileArgs &a, int tile_waves, hipStream_t st, hipEvent_t start, hipEvent_t done)
+{
+    const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
+    if (n_tiles == 0) return 0;
+    if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
+    if (tile_waves == 16) return launch_tile_waves<16>(fs, a, n_tiles, st, start, done);
+    if (tile_waves == 8) return launch_tile_waves<8>(fs, a, n_tiles, st, start, done);
+    if (tile_waves == 4) return launch_tile_waves<4>(fs, a, n_tiles, st, start, done);
+    return (int)hipErrorInvalidValue;
 }
 
 int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st)

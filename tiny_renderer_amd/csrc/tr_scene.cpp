@@ -79,6 +79,13 @@ struct EventPair {
 
 }  // namespace
 
+// How many passes the setup stream may run ahead of the tile kernels: setup of pass p waits for the
+// tile kernel of pass p - LOOKAHEAD only.  With 2 the setup chain (k_setup, k_order_count,
+// k_order_place: ~35 us beside a busy machine) had to fit inside one tile kernel (~34 us) and was
+// the critical path of the frame loop; 3 gives it two.
+constexpr int LOOKAHEAD = 3;
+constexpr int SETS = LOOKAHEAD + 1;
+
 struct tr_scene {
     uint32_t width = 0, height = 0;
     int pipeline = 0;
@@ -107,16 +114,17 @@ struct tr_scene {
     // reads set `cur`, its tile kernel zeroes the other set for the next pass of the same kind.
     // Colour passes (the scene's band) and depth passes (always the whole frame) have different
     // tile grids, hence a state each.
-    // Three sets: while the tile kernel of pass q reads set q % 3 and zeroes set (q + 2) % 3, the
-    // setup kernel of pass q + 1 (running beside it on the setup stream) fills set (q + 1) % 3.
+    // SETS sets: the tile kernel of pass q zeroes set (q + SETS - 1) % SETS, which no pass before
+    // q + SETS - 1 touches; meanwhile the setup kernels of passes q + 1 and q + 2 (running ahead on
+    // the setup stream, see LOOKAHEAD) fill sets (q + 1) % SETS and (q + 2) % SETS.
     struct BinState {
-        uint32_t *count[3] = { nullptr, nullptr, nullptr };
+        uint32_t *count[SETS] = {};
         uint64_t seq = 0;           // passes of this kind issued so far
     } bin_color, bin_depth;
-    // Record bins, double buffered by global pass number: pass p's setup fills bins[p % 2] while
-    // pass p - 1's tile kernel is still reading bins[(p - 1) % 2].
-    WorkItem *d_order[2] = { nullptr, nullptr };  // the tile kernel's work list (k_order), buffered like the bins
-    Piece *d_bins[2] = { nullptr, nullptr };  // each n_tiles_full x bin_cap records of rec_pieces x 16 B
+    // Record bins and work lists, LOOKAHEAD-buffered by global pass number: pass p's setup fills
+    // bins[p % LOOKAHEAD] while the tile kernels of passes p - 1 and p - 2 may still be reading theirs.
+    WorkItem *d_order[LOOKAHEAD] = {};  // the tile kernel's work list (k_order)
+    Piece *d_bins[LOOKAHEAD] = {};      // each n_tiles_full x bin_cap records of rec_pieces x 16 B
     // Pass pipelining: k_setup of pass p runs on `setup_stream`, ordered after the tile kernel of
     // pass p - 2 (which frees its bins and zeroed its counters) and before the tile kernel of pass p
     // on the main stream.  It needs only frame constants, so it overlaps the tile kernel of pass
@@ -125,6 +133,7 @@ struct tr_scene {
     hipEvent_t ev_setup[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev_tile[4] = { nullptr, nullptr, nullptr, nullptr };
     uint64_t pass_seq = 0;
+    uint32_t tile_waves = 0;     // tr_options.tile_waves: 4, 8 or 0 = by tile count
     uint32_t bin_cap = 0;        // records per tile; grown on overflow
     uint32_t rec_pieces = 0;
     uint32_t *d_bin_need = nullptr;
@@ -291,7 +300,7 @@ int recover_from_overflow(tr_scene *s)
     HIP_TRY(hipStreamSynchronize(s->setup_stream));
     s->bin_cap = (uint32_t)cap;
     int st = TR_OK;
-    for (int k = 0; k < 2 && st == TR_OK; k++) {
+    for (int k = 0; k < LOOKAHEAD && st == TR_OK; k++) {
         dev_free(s->d_bins[k]);
         st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces);
     }
@@ -393,9 +402,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.frame = frame;
     sa.u = du;
     tr_scene::BinState &bs = depth_pass ? s->bin_depth : s->bin_color;
-    const int set_cur = (int)(bs.seq % 3), set_zero = (int)((bs.seq + 2) % 3);
+    const int set_cur = (int)(bs.seq % SETS), set_zero = (int)((bs.seq + SETS - 1) % SETS);
     const uint64_t p_seq = s->pass_seq;
-    Piece *bins = s->d_bins[p_seq % 2];
+    Piece *bins = s->d_bins[p_seq % LOOKAHEAD];
     sa.tile_count = bs.count[set_cur];
     sa.bins = bins;
     sa.bin_cap = s->bin_cap;
@@ -403,12 +412,13 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
     // setup on its own stream: after the tile kernel of pass p - 2, before the tile kernel of pass p
-    if (p_seq >= 2) HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - 2) % 4], 0));
+    if (p_seq >= (uint64_t)LOOKAHEAD)
+        HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % 4], 0));
     const uint32_t n_tiles_pass = frame.ntx * frame.nty;
     if (!s->profiling) {
         int rc = launch_setup(p.vs, sa, s->setup_stream, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % 2], n_tiles_pass, s->setup_stream, nullptr,
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, s->setup_stream, nullptr,
                           s->ev_setup[p_seq % 4]);
         if (rc) return launch_status(rc, "k_order");
     } else {
@@ -418,7 +428,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
         if (rc) return launch_status(rc, "k_setup");
         if (s->mesh.n_tri) s->events.push_back(ep);
         EventPair eo = { take_event(s), take_event(s), K_ORDER };
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % 2], n_tiles_pass, s->setup_stream, eo.a, eo.b);
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, s->setup_stream, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
         s->events.push_back(eo);
         HIP_TRY(hipEventRecord(s->ev_setup[p_seq % 4], s->setup_stream));
@@ -429,7 +439,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.bins = bins;
     ta.bin_cap = s->bin_cap;
     ta.rec_pieces = s->rec_pieces;
-    ta.order = s->d_order[p_seq % 2];
+    ta.order = s->d_order[p_seq % LOOKAHEAD];
     ta.tile_count_next = bs.count[set_zero];
     ta.frame = frame;
     ta.u = du;
@@ -444,12 +454,17 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
+    // More waves per tile shorten the serial work of each and multiply the waves a tile brings:
+    // faster while the tiles with polygons cannot fill the GPU (1536 workgroup slots at four waves),
+    // slower beyond (more total work).  Measured on diablo (k_tile, us, 4 / 8 / 16 waves): 800^2
+    // 97 / 65 / 46, 1024^2 76 / 53 / 37, 2048^2 42 / 31 / 27, 4096^2 36 / 44 / 74.
+    const int tile_waves = s->tile_waves ? (int)s->tile_waves : n_tiles_pass <= 2048u ? 16 : n_tiles_pass <= 4096u ? 8 : 4;
     if (!s->profiling) {
-        int rc = launch_tile(p.fs, ta, s->stream, nullptr, s->ev_tile[p_seq % 4]);
+        int rc = launch_tile(p.fs, ta, tile_waves, s->stream, nullptr, s->ev_tile[p_seq % 4]);
         if (rc) return launch_status(rc, "k_tile");
     } else {
         EventPair ep = { take_event(s), take_event(s), depth_pass ? K_TILE_DEPTH : K_TILE };
-        int rc = launch_tile(p.fs, ta, s->stream, ep.a, ep.b);
+        int rc = launch_tile(p.fs, ta, tile_waves, s->stream, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_tile");
         s->events.push_back(ep);
         HIP_TRY(hipEventRecord(s->ev_tile[p_seq % 4], s->stream));
@@ -501,14 +516,14 @@ void destroy(tr_scene *s)
     }
     if (s->setup_stream) (void)hipStreamDestroy(s->setup_stream);
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < SETS; k++) {
             dev_free(b->count[k]);
         }
     }
-    dev_free(s->d_order[0]);
-    dev_free(s->d_order[1]);
-    dev_free(s->d_bins[0]);
-    dev_free(s->d_bins[1]);
+    for (int k = 0; k < LOOKAHEAD; k++) {
+        dev_free(s->d_order[k]);
+        dev_free(s->d_bins[k]);
+    }
     dev_free(s->d_bin_need);
     dev_free(s->d_z);
     dev_free(s->d_shadow);
@@ -558,6 +573,9 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->height = height;
     s->pipeline = pipe;
     s->flags = o.flags;
+    if (o.tile_waves != 0 && o.tile_waves != 4 && o.tile_waves != 8 && o.tile_waves != 16)
+        return tr::fail(TR_E_INVALID, "tile_waves must be 0, 4, 8 or 16");
+    s->tile_waves = o.tile_waves;
 
     if (o.stream) {
         s->stream = (hipStream_t)o.stream;
@@ -615,13 +633,13 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     // bins
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
         const size_t nt = (b == &s->bin_color) ? s->n_tiles : s->n_tiles_full;
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < SETS; k++) {
             // nt counters, then k_order's 8 bucket sizes and 8 cursors
             if ((st = dev_alloc(&b->count[k], nt + 16))) return st;
             HIP_TRY(hipMemset(b->count[k], 0, (nt + 16) * 4));
         }
     }
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < LOOKAHEAD; k++)
         if ((st = dev_alloc(&s->d_order[k], (size_t)s->n_tiles_full))) return st;
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
     uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
@@ -629,7 +647,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if (cap < 64) cap = 64;
     s->bin_cap = (uint32_t)cap;
     s->rec_pieces = (pipe == P_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < LOOKAHEAD; k++)
         if ((st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
     HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream, hipStreamNonBlocking));
     for (int k = 0; k < 4; k++) {

@@ -49,15 +49,11 @@ constexpr int TILE_W = 128;
 #define TR_TILE_H 16
 #endif
 constexpr int TILE_H = TR_TILE_H;
-// Wavefronts per tile workgroup.  Each owns a TILE_W / TILE_WAVES pixel wide column of the tile
-// during coverage; for shading the tile is re-divided into 32-pixel wide strips so that every
-// row a wave stores is whole cache lines.
-#ifndef TR_TILE_WAVES
-#define TR_TILE_WAVES 4
-#endif
-constexpr int TILE_WAVES = TR_TILE_WAVES;
-constexpr int TILE_THREADS = 64 * TILE_WAVES;
-constexpr int QUAD = TILE_W / TILE_WAVES;
+// Wavefronts per tile workgroup: 4, 8 or 16, chosen per launch (launch_tile).  Each owns a
+// TILE_W / waves pixel wide column of the tile during coverage; for shading the tile is re-divided
+// into 32-pixel wide strips so that every row a wave stores is whole cache lines.  Four waves do
+// the least total work and win when the busy tiles fill the machine (4096^2 and up); more waves
+// shorten the serial work per wave and win when they do not (2048^2: 42 -> 27 us with sixteen).
 constexpr int STRIP = 32;
 
 // Raster part of a polygon record (64 B).  Mirrors Buffer.vertex_t_raster / vertex_z_values

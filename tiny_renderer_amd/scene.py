@@ -38,7 +38,7 @@ class Scene:
 
     def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
                  winner_tap=False, tile_stamps=False, band_rows=None, stream=None, frame_buffer_device=None,
-                 bin_capacity=0):
+                 bin_capacity=0, tile_waves=0):
         L = load_library()
         self.width, self.height = int(width), int(height)
         keep = []
@@ -59,6 +59,7 @@ class Scene:
         o.stream = stream
         o.frame_buffer_device = frame_buffer_device
         o.bin_capacity = int(bin_capacity)
+        o.tile_waves = int(tile_waves)
         h = C.c_void_p()
         self._h = None
         check(L.tr_scene_create(self.width, self.height, C.byref(m), imgs,
