@@ -241,7 +241,8 @@ def main():
                     # (FETCH_SIZE x2 + WRITE_SIZE, see profiles/pmc_traffic.json); null when this
                     # workload has not been profiled
                     entry = json.load(open(tf)).get(workload, {})
-                    traffic = entry.get("hbm_bytes_per_launch") if entry.get("kernel") == dom else None
+                    # (profiled on one GPU: a band-sharded launch moves a different amount)
+                    traffic = entry.get("hbm_bytes_per_launch") if entry.get("kernel") == dom and world == 1 else None
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
