@@ -89,3 +89,64 @@ def test_resolve_matches_serial_order_gpu(built, seed):
     assert np.array_equal(fb, s.get_frame_buffer())
     if pipe in ("shadow", "occlusion"):
         assert np.array_equal(g.read_shadow_f32().view(np.uint32), s.shadow_f32().view(np.uint32))
+
+
+def far_soup(seed, n_tri):
+    """Polygons that stress the f32 rounding of the edge functions: vertices far outside the frame
+    (raster coordinates up to ~3e8, products far beyond 2^24), long slivers crossing the screen,
+    nearly collinear triples, mixed with ordinary small polygons."""
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((n_tri, 3, 3), F)
+    for i in range(n_tri):
+        kind = i % 4
+        reach = F(10.0 ** rng.uniform(0, 5))                       # 1 .. 1e5 object units
+        if kind == 0:                                              # huge, vertices far away
+            pts[i, :, :2] = rng.uniform(-1, 1, (3, 2)) * reach
+        elif kind == 1:                                            # sliver: two near vertices, one far
+            p = rng.uniform(-1, 1, 2)
+            pts[i, 0, :2] = p
+            pts[i, 1, :2] = p + rng.uniform(-1, 1, 2) * 10.0 ** rng.uniform(-4, -1)
+            pts[i, 2, :2] = rng.uniform(-1, 1, 2) * reach
+        elif kind == 2:                                            # nearly collinear
+            a, b = rng.uniform(-1, 1, 2) * reach, rng.uniform(-1, 1, 2) * reach
+            t = rng.uniform(0.2, 0.8)
+            pts[i, 0, :2], pts[i, 1, :2] = a, b
+            pts[i, 2, :2] = a + t * (b - a) + rng.uniform(-1, 1, 2) * 10.0 ** rng.uniform(-3, 0)
+        else:                                                      # ordinary
+            pts[i, :, :2] = rng.uniform(-1, 1, 2) + rng.uniform(-0.2, 0.2, (3, 2))
+        pts[i, :, 2] = rng.uniform(-0.5, 0.5, 3)
+    pos = pts.reshape(-1, 3)
+    nrm = rng.standard_normal((n_tri * 3, 3)).astype(F)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tex = np.concatenate([rng.uniform(0.05, 0.95, (n_tri * 3, 2)).astype(F), np.zeros((n_tri * 3, 1), F)], 1)
+    idx = np.arange(n_tri * 3, dtype=np.uint32).reshape(n_tri, 3).repeat(3, axis=1)
+    texs = [rng.integers(0, 256, (32, 32, 3), dtype=np.uint8) for _ in range(4)]
+    return {"pos": pos, "tex": tex, "nrm": nrm, "idx": idx}, texs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(9))
+def test_far_vertices_and_slivers_gpu(built, seed):
+    """The tile kernel drops 8x8 blocks that lie outside an edge by more than a rounding margin
+    before testing pixels: with far-away vertices the edge functions round in f32 (products up to
+    ~1e17), so this is where a margin that is too small would lose fragments.  Wide frames keep the
+    screen coordinates themselves large, too."""
+    import tiny_renderer_amd as T
+    W, Hh = [(8192, 48), (4096, 130), (1000, 1000)][seed % 3]
+    waves = [4, 8, 16][(seed // 3) % 3]
+    pipe = ["phong", "normal_map", "default"][seed % 3]  # (no shadow-buffer lookups: they would leave their range)
+    mesh, texs = far_soup(5000 + seed, 160)
+    err, s = oracle_frame(W, Hh, mesh, texs, pipe, 0.0, 0.4)
+    if err:
+        pytest.skip("the reference would panic on this soup")
+    g = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_waves=waves)
+    g.clear()
+    g.set_light_direction(H.light(0.4))
+    g.set_camera(*H.camera(0.0))
+    g.render()
+    fb = g.get_frame_buffer()
+    wo, wg = s.winner_u32(), g.read_winner_u32()
+    assert (wo != 0xFFFFFFFF).sum() > 1000
+    assert np.array_equal(wg, wo), "winner differs at %d pixels" % int((wg != wo).sum())
+    assert np.array_equal(g.read_z_f32().view(np.uint32), s.z_f32().view(np.uint32))
+    assert np.array_equal(fb, s.get_frame_buffer())
