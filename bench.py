@@ -172,6 +172,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- metric 2: frames/s with the camera orbiting by 2*pi/200 per frame ---------
+    # (deterministic stand-in for the reference's keyboard orbit, app.rs:173-200); not `value`.
+    orbit_frames = 200
+
+    def orbit_step(i):
+        scene.clear()
+        scene.set_light_direction(lt)
+        scene.set_camera(*camera(2.0 * np.pi * i / orbit_frames))
+        scene.render()
+        if use_dist:
+            dist.all_gather_into_tensor(fb, chunk)
+
+    for i in range(orbit_frames):   # warm-up lap: lets the bins grow to what every angle needs
+        orbit_step(i)
+    scene.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(orbit_frames):
+        orbit_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    orbit_elapsed = time.perf_counter() - t1
+    orbit_status = scene.sync()
+    step()  # back to the headline frame for the parity check below
+    torch.cuda.synchronize()
+
     # ---- per-kernel device time of the same step, HIP events on the scene's stream ------------
     scene.profile_enable(True)
     for _ in range(args.steps):
@@ -265,6 +292,7 @@ def main():
                        "polygons": int(mesh["idx"].shape[0]),
                        "sharding": "screen row bands + RCCL all-gather of the framebuffer" if use_dist else "none"},
             "frames_per_s": round(args.steps / elapsed, 1),
+            "frames_per_s_orbit": round(orbit_frames / orbit_elapsed, 1) if orbit_status == 0 else None,
             "framebuffer_mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
             "parity_vs_oracle": {"ok": parity_ok, "max_abs_rgb_diff": int(diff.max()), "tolerance": tol},
             "device_status": status,

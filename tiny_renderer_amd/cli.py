@@ -19,6 +19,11 @@ def main(argv=None):
     ap.add_argument("--camera-angle", type=float, default=0.0, help="app.rs:158, radians")
     ap.add_argument("--light-angle", type=float, default=0.0, help="app.rs:159, radians")
     ap.add_argument("--frames", type=int, default=1, help="frames to render (camera orbits 2*pi over them)")
+    ap.add_argument("--seconds", type=float, default=0.0,
+                    help="run the reference's time-based frame loop for this long instead (app.rs:166-247): the "
+                         "camera turns at CAMERA_SPEED = 3 rad/s as if a key were held, `FPS --- n` every second")
+    ap.add_argument("--no-readback", action="store_true",
+                    help="with --seconds: leave the frames on the GPU (the reference hands every frame to its window)")
     ap.add_argument("--out", default=None, help="write the last frame as PPM")
     ap.add_argument("--view", choices=("frame", "z", "shadow"), default="frame")  # app.rs:213-215
     ap.add_argument("--device", type=int, default=-1)
@@ -36,6 +41,40 @@ def main(argv=None):
     print("number of polygons in a model: %d" % mesh["idx"].shape[0])
     print("cooking up a scene with '%s' shader pipeline" % args.pipeline)
     scene = T.Scene(args.width, args.height, mesh, texs, args.pipeline, device=args.device)
+
+    if args.seconds > 0:
+        # app.rs:12-13,160-165,173-199,230-246: angles advance by speed * frame time; a frame counter is
+        # printed and reset whenever more than a second has passed
+        camera_speed = 3.0
+        ca, la = np.float32(args.camera_angle), np.float32(args.light_angle)
+        start = last = fps_t = time.perf_counter()
+        fps_counter, img = 0, None
+        while True:
+            now = time.perf_counter()
+            if now - start >= args.seconds:
+                break
+            ca = np.float32(ca + camera_speed * (now - last))
+            last = now
+            scene.clear()
+            scene.set_light_direction([float(np.sin(la)), 0.0, float(np.cos(la))])
+            scene.set_camera([float(np.sin(ca)), 0.0, float(np.cos(ca))], [0, 0, 0], [0, 1, 0])
+            scene.render()
+            if not args.no_readback:
+                img = scene.get_frame_buffer()
+            elif fps_counter % 64 == 63:
+                scene.sync()  # keep the queue bounded
+            fps_counter += 1
+            if now - fps_t > 1.0:
+                print("FPS --- %d" % fps_counter)
+                fps_counter, fps_t = 0, now
+        scene.sync()
+        if args.out:
+            img = {"frame": scene.get_frame_buffer, "z": scene.get_z_buffer, "shadow": scene.get_shadow_buffer}[args.view]()
+            with open(args.out, "wb") as fh:
+                fh.write(b"P6\n%d %d\n255\n" % (args.width, args.height))
+                fh.write(img.tobytes())
+            print("wrote %s" % args.out)
+        return 0
 
     t0 = time.perf_counter()
     for f in range(args.frames):
