@@ -112,6 +112,15 @@ int tr_scene_read_shadow_f32(tr_scene *s, float *out);
 int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out); /* needs TR_OPT_WINNER_TAP;
                                                              0xFFFFFFFF = no fragment */
 
+/* Streaming frames out (the reference hands every frame to its window, app.rs:213-218): enqueue
+ * the device-to-host copy of the frame behind the renders issued so far and return at once; `rgb`
+ * (3*W*H bytes, row 0 = top) holds the frame after tr_scene_sync().  With memory from
+ * tr_host_alloc (page-locked) the copy runs at PCIe speed and the host is free meanwhile; a later
+ * render is ordered after the copy. */
+int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb);
+void *tr_host_alloc(size_t bytes); /* page-locked host memory, NULL on failure */
+void tr_host_free(void *p);
+
 /* Device-resident access for callers that keep the frame on the GPU. */
 int tr_scene_sync(tr_scene *s);                 /* wait for queued work; returns frame status */
 void *tr_scene_frame_buffer_device(tr_scene *s); /* 3*W*H bytes, row 0 = top */

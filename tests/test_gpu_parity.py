@@ -171,6 +171,35 @@ def test_initial_state_and_clear_only(small_synthetic):
     assert np.all(s.get_frame_buffer() == 0) and np.all(s.get_z_buffer() == 0)
 
 
+def test_async_frame_readback(small_synthetic):
+    """tr_scene_get_frame_buffer_async: read-backs queued behind their frames, no host wait between
+    frames; every copy holds its own frame after one sync."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 640, 360
+    gpu = T.Scene(W, Hh, mesh, texs, "phong")
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    outs = [gpu.pinned_frame() for _ in range(3)]
+    for k, out in enumerate(outs):
+        gpu.clear()
+        gpu.set_light_direction(H.light(0.2 * k))
+        gpu.set_camera(*H.camera(0.5 * k))
+        gpu.render()
+        gpu.get_frame_buffer_async(out)
+    assert gpu.sync() == 0
+    for k, out in enumerate(outs):
+        cpu.clear()
+        cpu.set_light_direction(H.light(0.2 * k))
+        cpu.set_camera(*H.camera(0.5 * k))
+        assert cpu.render() == 0
+        assert np.array_equal(out, cpu.get_frame_buffer()), "frame %d" % k
+    gpu.clear()   # a clear that is read back before any render
+    gpu.get_frame_buffer_async(outs[0])
+    assert gpu.sync() == 0 and not outs[0].any()
+    gpu.close()
+
+
 def test_depth_views(small_synthetic):
     """get_z_buffer / get_shadow_buffer (scene.rs:101-125)."""
     mesh, texs = small_synthetic

@@ -69,6 +69,9 @@ SYMBOLS = {
     "tr_scene_set_camera": (C.c_int, [C.c_void_p, _FP, _FP, _FP]),
     "tr_scene_render": (C.c_int, [C.c_void_p]),
     "tr_scene_get_frame_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_get_frame_buffer_async": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "tr_host_free": (None, [C.c_void_p]),
     "tr_scene_get_z_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_get_shadow_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_read_z_f32": (C.c_int, [C.c_void_p, C.c_void_p]),

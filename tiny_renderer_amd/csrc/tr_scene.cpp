@@ -842,6 +842,29 @@ int tr_scene_get_frame_buffer(tr_scene *s, uint8_t *rgb)
     return read_back(s, rgb, s->d_fb, (size_t)s->width * s->height * 3);
 }
 
+int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
+{
+    if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    // same stream as the tile kernels: after the frame, before the next one overwrites it
+    HIP_TRY(hipMemcpyAsync(rgb, s->d_fb, (size_t)s->width * s->height * 3, hipMemcpyDeviceToHost, s->stream));
+    return TR_OK;
+}
+
+void *tr_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void tr_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb)
 {
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");

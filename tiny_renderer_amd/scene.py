@@ -62,6 +62,7 @@ class Scene:
         o.tile_waves = int(tile_waves)
         h = C.c_void_p()
         self._h = None
+        self._pinned = []
         check(L.tr_scene_create(self.width, self.height, C.byref(m), imgs,
                                 shader_pipeline_name.encode(), C.byref(o), C.byref(h)))
         self._h = h
@@ -69,8 +70,11 @@ class Scene:
 
     def close(self):
         if getattr(self, "_h", None):
-            load_library().tr_scene_destroy(self._h)
+            load_library().tr_scene_destroy(self._h)   # waits for queued work, pending read-backs included
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                load_library().tr_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -101,6 +105,23 @@ class Scene:
 
     def get_frame_buffer(self, strict=True):
         return self._image("tr_scene_get_frame_buffer", strict)
+
+    def pinned_frame(self):
+        """A page-locked [H, W, 3] uint8 array for get_frame_buffer_async (freed with the scene)."""
+        L = load_library()
+        n = self.width * self.height * 3
+        p = L.tr_host_alloc(n)
+        if not p:
+            raise MemoryError("tr_host_alloc(%d)" % n)
+        self._pinned.append(p)
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)).reshape(self.height, self.width, 3)
+
+    def get_frame_buffer_async(self, out):
+        """Enqueue the read-back of the frame into `out` (see pinned_frame); valid after sync()."""
+        if out.nbytes != self.width * self.height * 3 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a contiguous [H, W, 3] uint8 array")
+        check(load_library().tr_scene_get_frame_buffer_async(self._h, out.ctypes.data))
+        return out
 
     def get_z_buffer(self, strict=True):
         return self._image("tr_scene_get_z_buffer", strict)
