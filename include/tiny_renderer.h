@@ -173,6 +173,9 @@ int tr_load_obj(const char *path, tr_mesh **out);
 void tr_free_mesh(tr_mesh *m);
 int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out);
 void tr_free_image(tr_image_rgb8 *img);
+/* Frame writer (no counterpart upstream: the reference shows frames in a window): uncompressed
+ * 24-bit TGA, top-left origin, i.e. exactly what tr_scene_get_frame_buffer returns. */
+int tr_save_tga_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h);
 
 const char *tr_last_error(void);
 int tr_abi_version(void);

@@ -92,6 +92,7 @@ SYMBOLS = {
     "tr_free_mesh": (None, [C.POINTER(Mesh)]),
     "tr_load_tga_rgb8": (C.c_int, [C.c_char_p, C.POINTER(ImageRgb8)]),
     "tr_free_image": (None, [C.POINTER(ImageRgb8)]),
+    "tr_save_tga_rgb8": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "tr_last_error": (C.c_char_p, []),
     "tr_abi_version": (C.c_int, []),
 }

@@ -39,6 +39,12 @@ def load_tga(path):
         L.tr_free_image(C.byref(img))
 
 
+def save_tga(path, rgb):
+    """Write an [H, W, 3] uint8 frame (row 0 = top, as get_frame_buffer returns it) as a 24-bit TGA."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    check(load_library().tr_save_tga_rgb8(os.fsencode(path), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
+
+
 def load_assets(asset_path):
     """-p <asset dir>: returns (mesh, [texture, normal_map, normal_map_tangent, specular_map])."""
     mesh = load_obj(os.path.join(asset_path, ASSET_FILES[0]))

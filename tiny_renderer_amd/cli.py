@@ -24,7 +24,7 @@ def main(argv=None):
                          "camera turns at CAMERA_SPEED = 3 rad/s as if a key were held, `FPS --- n` every second")
     ap.add_argument("--no-readback", action="store_true",
                     help="with --seconds: leave the frames on the GPU (the reference hands every frame to its window)")
-    ap.add_argument("--out", default=None, help="write the last frame as PPM")
+    ap.add_argument("--out", default=None, help="write the last frame: .tga (24-bit) or binary PPM otherwise")
     ap.add_argument("--view", choices=("frame", "z", "shadow"), default="frame")  # app.rs:213-215
     ap.add_argument("--device", type=int, default=-1)
     ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of -p")
@@ -70,10 +70,7 @@ def main(argv=None):
         scene.sync()
         if args.out:
             img = {"frame": scene.get_frame_buffer, "z": scene.get_z_buffer, "shadow": scene.get_shadow_buffer}[args.view]()
-            with open(args.out, "wb") as fh:
-                fh.write(b"P6\n%d %d\n255\n" % (args.width, args.height))
-                fh.write(img.tobytes())
-            print("wrote %s" % args.out)
+            write_frame(T, args.out, img)
         return 0
 
     t0 = time.perf_counter()
@@ -88,11 +85,18 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     print("FPS --- %d" % int(args.frames / dt if dt > 0 else 0))              # app.rs:238
     if args.out:
-        with open(args.out, "wb") as fh:
-            fh.write(b"P6\n%d %d\n255\n" % (args.width, args.height))
-            fh.write(img.tobytes())
-        print("wrote %s" % args.out)
+        write_frame(T, args.out, img)
     return 0
+
+
+def write_frame(T, path, img):
+    if path.lower().endswith(".tga"):
+        T.save_tga(path, img)
+    else:
+        with open(path, "wb") as fh:
+            fh.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+            fh.write(img.tobytes())
+    print("wrote %s" % path)
 
 
 if __name__ == "__main__":

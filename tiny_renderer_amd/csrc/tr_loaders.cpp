@@ -163,8 +163,9 @@ extern "C" void tr_free_mesh(tr_mesh *mesh)
     if (mesh) delete reinterpret_cast<MeshOwner *>(mesh);
 }
 
-// TGA: image types 2 (true colour), 3 (grey), 10 / 11 (their run-length forms); 8, 24 or 32
-// bits per pixel; either vertical origin.  Colour-mapped and 15/16-bit files are rejected.
+// TGA: image types 1 (colour-mapped), 2 (true colour), 3 (grey) and 9 / 10 / 11 (their run-length
+// forms); 8-bit indices into a 24- or 32-bit palette, 24- or 32-bit true colour, 8-bit grey; either
+// origin.  15/16-bit pixels or palettes are rejected.
 extern "C" int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out)
 {
     if (!path || !out) return tr::fail(TR_E_INVALID, "tr_load_tga_rgb8: null argument");
@@ -176,13 +177,19 @@ extern "C" int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out)
     const uint32_t id_len = d[0], cmap_type = d[1], type = d[2];
     const uint32_t cmap_len = d[5] | (d[6] << 8), cmap_bits = d[7];
     const uint32_t w = d[12] | (d[13] << 8), h = d[14] | (d[15] << 8), bpp = d[16], desc = d[17];
-    const bool rle = (type == 10 || type == 11), grey = (type == 3 || type == 11);
-    if (!(type == 2 || type == 3 || type == 10 || type == 11))
+    const bool rle = (type == 9 || type == 10 || type == 11), grey = (type == 3 || type == 11);
+    const bool mapped = (type == 1 || type == 9);
+    if (!(type == 1 || type == 2 || type == 3 || type == 9 || type == 10 || type == 11))
         return tr::fail(TR_E_FORMAT, std::string("unsupported TGA image type in ") + path);
-    if ((grey && bpp != 8) || (!grey && bpp != 24 && bpp != 32))
+    if (((grey || mapped) && bpp != 8) || (!grey && !mapped && bpp != 24 && bpp != 32))
         return tr::fail(TR_E_FORMAT, std::string("unsupported TGA pixel depth in ") + path);
+    if (mapped && (cmap_type != 1 || (cmap_bits != 24 && cmap_bits != 32)))
+        return tr::fail(TR_E_FORMAT, std::string("unsupported TGA colour map in ") + path);
     const size_t bytes_pp = bpp / 8, npx = (size_t)w * h;
-    size_t pos = 18 + id_len + (cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0);
+    const uint32_t cmap_first = d[3] | (d[4] << 8);
+    const size_t cmap_entry = (cmap_bits + 7) / 8, cmap_pos = 18 + id_len;
+    size_t pos = cmap_pos + (cmap_type ? (size_t)cmap_len * cmap_entry : 0);
+    if (pos > d.size()) return tr::fail(TR_E_FORMAT, std::string("truncated TGA colour map: ") + path);
 
     std::vector<uint8_t> raw(npx * bytes_pp);
     if (!rle) {
@@ -219,6 +226,17 @@ extern "C" int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out)
             uint8_t *t = &rgb[((size_t)y * w + x) * 3];
             if (grey) {
                 t[0] = t[1] = t[2] = s[0];
+            } else if (mapped) {
+                // palette entries are stored b, g, r(, a) like true-colour pixels
+                const uint32_t k = s[0] >= cmap_first ? s[0] - cmap_first : cmap_len;
+                if (k >= cmap_len) {
+                    free(rgb);
+                    return tr::fail(TR_E_FORMAT, std::string("TGA palette index out of range in ") + path);
+                }
+                const uint8_t *c = &d[cmap_pos + (size_t)k * cmap_entry];
+                t[0] = c[2];
+                t[1] = c[1];
+                t[2] = c[0];
             } else {
                 t[0] = s[2];
                 t[1] = s[1];
@@ -229,6 +247,32 @@ extern "C" int tr_load_tga_rgb8(const char *path, tr_image_rgb8 *out)
     out->rgb = rgb;
     out->w = w;
     out->h = h;
+    return TR_OK;
+}
+
+// Frame writer (the reference has none: it shows frames in a window): uncompressed 24-bit
+// true-colour TGA, top-left origin -- the layout of get_frame_buffer.
+extern "C" int tr_save_tga_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h)
+{
+    if (!path || (!rgb && w && h)) return tr::fail(TR_E_INVALID, "tr_save_tga_rgb8: null argument");
+    if (w > 65535u || h > 65535u) return tr::fail(TR_E_INVALID, "tr_save_tga_rgb8: a TGA side is at most 65535");
+    FILE *f = fopen(path, "wb");
+    if (!f) return tr::fail(TR_E_IO, std::string("cannot write ") + path);
+    uint8_t hd[18] = { 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, (uint8_t)(w & 0xFF), (uint8_t)(w >> 8),
+                       (uint8_t)(h & 0xFF), (uint8_t)(h >> 8), 24, 0x20 };
+    bool ok = fwrite(hd, 1, sizeof hd, f) == sizeof hd;
+    std::vector<uint8_t> row((size_t)w * 3);
+    for (uint32_t y = 0; y < h && ok; y++) {
+        const uint8_t *s = rgb + (size_t)y * w * 3;
+        for (uint32_t x = 0; x < w; x++) {
+            row[3 * x] = s[3 * x + 2];
+            row[3 * x + 1] = s[3 * x + 1];
+            row[3 * x + 2] = s[3 * x];
+        }
+        ok = row.empty() || fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return tr::fail(TR_E_IO, std::string("short write to ") + path);
     return TR_OK;
 }
 
