@@ -73,8 +73,13 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
         if (r.bx0 <= r.bx1) {
             uint4 *o = s_rec + lane * P;
             o[0] = make_uint4((uint32_t)r.bx0, (uint32_t)r.bx1, (uint32_t)r.by0, (uint32_t)r.by1);
-            o[1] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, (uint32_t)r.x1, (uint32_t)r.y1);
-            o[2] = make_uint4((uint32_t)r.x2, (uint32_t)r.y2, __float_as_uint(r.z0), __float_as_uint(r.z1));
+            // vertex 0 and the two edge vectors from it, the latter already as the f32 values every
+            // pixel's to_barycentric_coord starts from (scene.rs:178-181: integer difference, then
+            // the conversion) -- the tile kernel's shading phase used to redo these 8 subtractions
+            // and 8 conversions for every pixel pair
+            const Edge e = edge_setup(r);
+            o[1] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, __float_as_uint(e.a0), __float_as_uint(e.b0));
+            o[2] = make_uint4(__float_as_uint(e.a1), __float_as_uint(e.b1), __float_as_uint(r.z0), __float_as_uint(r.z1));
             o[3] = make_uint4(__float_as_uint(r.z2), t, __float_as_uint(v[0]), __float_as_uint(v[1]));
 #pragma unroll
             for (int i = 4; i < P; i++)
@@ -427,8 +432,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             // cross.z > 0: negating a0, a1, b0, b1 flips the sign of cross.x and cross.y exactly,
             // and dividing them by -cross.z (reciprocal -y) gives bit-identical quotients, so one
             // branch-free form of the inside test serves both windings.
-            float la0 = (float)isub((int32_t)r1.z, (int32_t)r1.x), la1 = (float)isub((int32_t)r2.x, (int32_t)r1.x);
-            float lb0 = (float)isub((int32_t)r1.w, (int32_t)r1.y), lb1 = (float)isub((int32_t)r2.y, (int32_t)r1.y);
+            float la0 = __uint_as_float(r1.z), la1 = __uint_as_float(r2.x);
+            float lb0 = __uint_as_float(r1.w), lb1 = __uint_as_float(r2.y);
             float lcz = la0 * lb1 - la1 * lb0;
             float lry = __uint_as_float(ry);
             if (lcz < 0.0f) {
@@ -621,10 +626,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             }
             // to_barycentric_coord for both pixels (each against its own polygon)
             Edge2 e;
-            e.a0 = mk2((float)isub((int32_t)qa[1].z, (int32_t)qa[1].x), (float)isub((int32_t)qb[1].z, (int32_t)qb[1].x));
-            e.a1 = mk2((float)isub((int32_t)qa[2].x, (int32_t)qa[1].x), (float)isub((int32_t)qb[2].x, (int32_t)qb[1].x));
-            e.b0 = mk2((float)isub((int32_t)qa[1].w, (int32_t)qa[1].y), (float)isub((int32_t)qb[1].w, (int32_t)qb[1].y));
-            e.b1 = mk2((float)isub((int32_t)qa[2].y, (int32_t)qa[1].y), (float)isub((int32_t)qb[2].y, (int32_t)qb[1].y));
+            e.a0 = mk2(__uint_as_float(qa[1].z), __uint_as_float(qb[1].z));
+            e.a1 = mk2(__uint_as_float(qa[2].x), __uint_as_float(qb[2].x));
+            e.b0 = mk2(__uint_as_float(qa[1].w), __uint_as_float(qb[1].w));
+            e.b1 = mk2(__uint_as_float(qa[2].y), __uint_as_float(qb[2].y));
             e.cz = e.a0 * e.b1 - e.a1 * e.b0;
             e.y = mk2(__uint_as_float(qa[P - 1].w), __uint_as_float(qb[P - 1].w));
             const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));

@@ -53,6 +53,11 @@ TR_HD f2 div_by2(f2 x, f2 d, f2 y)
     return mk2(x.x == 0.0f ? q0.x : q.x, x.y == 0.0f ? q0.y : q.y);
 }
 
+// The signed-zero repair of div_by as one bit operation: q0 = x * y always carries the sign of the
+// quotient (no underflow here: |x| >= 1 or x = 0, |y| >= 2^-62), and the corrected q differs from it
+// in sign only when x is a zero.
+TR_HD f2 quotient_sign_from(f2 q, f2 q0) { return mk2(copysignf(q.x, q0.x), copysignf(q.y, q0.y)); }
+
 // The same without the signed-zero repair: a quotient of a -0 numerator may come out as +0.
 // For consumers that only compare the result (or sums built from it) with IEEE ordering, where
 // +0 and -0 are the same value -- the coverage loop's depth test.

@@ -297,9 +297,9 @@ TR_HD Bary2 barycentric2(f2 cx, f2 cy, const Edge2 &e)
     qx = fma2(ex, e.y, qx);
     qy = fma2(ey, e.y, qy);
     Bary2 b;
-    b.x = splat2(1.0f) - mk2(s.x == 0.0f ? q0s.x : qs.x, s.y == 0.0f ? q0s.y : qs.y);
-    b.y = mk2(cx.x == 0.0f ? q0x.x : qx.x, cx.y == 0.0f ? q0x.y : qx.y);
-    b.z = mk2(cy.x == 0.0f ? q0y.x : qy.x, cy.y == 0.0f ? q0y.y : qy.y);
+    b.x = splat2(1.0f) - quotient_sign_from(qs, q0s);
+    b.y = quotient_sign_from(qx, q0x);
+    b.z = quotient_sign_from(qy, q0y);
     return b;
 }
 
