@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "tr_kernels.h"
 #include "tr_shaders.h"
 
@@ -592,6 +594,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t Wu = (uint32_t)W, W3 = 3u * (uint32_t)W;
     const bool col_live = px < W;
 
+    // The loop exists twice: for bins that stay resident in LDS (nearly all) and for the rare larger
+    // ones, whose survivors' records come from global memory -- a run-time choice inside the loop
+    // cost a dozen register moves per step where the two paths merge.
+    auto shade_steps = [&](auto in_lds) {
+    constexpr bool RESIDENT = decltype(in_lds)::value;
 #pragma unroll 1
     for (int32_t sstep = 0; sstep < NSTEP; sstep++) {
         int32_t row[2], py[2];
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         float zout[2] = { bits_f32(TR_F32_MIN_BITS), bits_f32(TR_F32_MIN_BITS) };
         if (__any(won[0] || won[1])) {
             uint4 qa[P], qb[P];
-            if (resident) {
+            if (RESIDENT) {
                 const uint4 *ra = s_rec + mul24(wslot[0], (uint32_t)P), *rb = s_rec + mul24(wslot[1], (uint32_t)P);
 #pragma unroll
                 for (int i = 1; i < P; i++) {
@@ -733,6 +740,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    };
+    if (resident)
+        shade_steps(std::true_type{});
+    else
+        shade_steps(std::false_type{});
 
     if (a.zclean && tid == 0u) a.zclean[tile] = 0u;
 
