@@ -171,6 +171,46 @@ def test_initial_state_and_clear_only(small_synthetic):
     assert np.all(s.get_frame_buffer() == 0) and np.all(s.get_z_buffer() == 0)
 
 
+def test_degenerate_inputs_and_lifetimes(small_synthetic):
+    """No polygons at all, a model entirely off screen, tear-down with frames still in flight, two
+    scenes interleaved on one device."""
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    empty = dict(mesh, idx=np.zeros((0, 9), np.uint32))
+    for pipe in ("phong", "shadow"):
+        s = T.Scene(300, 200, empty, texs, pipe, winner_tap=True)
+        s.clear()
+        s.render()
+        assert not s.get_frame_buffer().any()
+        assert (s.read_z_f32().view(np.uint32) == 0xFF7FFFFF).all() and (s.read_winner_u32() == 0xFFFFFFFF).all()
+        s.render()
+        assert s.sync() == 0
+        s.close()
+    far = dict(mesh, pos=mesh["pos"] + np.float32(1000.0))
+    s = T.Scene(300, 200, far, texs, "phong")
+    s.clear()
+    s.render()
+    assert not s.get_frame_buffer().any() and s.sync() == 0
+    s.close()
+    s = T.Scene(1024, 1024, mesh, texs, "phong")
+    for i in range(100):
+        s.clear()
+        s.set_camera(*H.camera(0.01 * i))
+        s.render()
+    s.close()  # frames still in flight
+    a, b = T.Scene(512, 512, mesh, texs, "phong"), T.Scene(640, 360, mesh, texs, "darboux")
+    for i in range(10):
+        for sc in (a, b):
+            sc.clear()
+            sc.set_camera(*H.camera(0.1 * i))
+            sc.render()
+    alone = T.Scene(512, 512, mesh, texs, "phong")
+    alone.clear()
+    alone.set_camera(*H.camera(0.9))
+    alone.render()
+    assert np.array_equal(a.get_frame_buffer(), alone.get_frame_buffer())
+
+
 def test_async_frame_readback(small_synthetic):
     """tr_scene_get_frame_buffer_async: read-backs queued behind their frames, no host wait between
     frames; every copy holds its own frame after one sync."""
