@@ -127,8 +127,11 @@ def main():
     cam, lt = camera(0.0), light(0.0)  # the state of the reference's first frame (app.rs:158-159)
 
     # ---- the scene on this rank -------------------------------------------------------------
-    stream = torch.cuda.current_stream().cuda_stream
+    # N > 1: the scene renders on torch's stream so that the all-gather is ordered behind it.
+    # N = 1: the library's own stream (its frame pipelining hands tile kernels over in batches there).
+    stream = torch.cuda.current_stream().cuda_stream if use_dist else None
     fb = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     band = None
     if use_dist:
         rows = [(r * H) // world for r in range(world + 1)]
@@ -154,17 +157,21 @@ def main():
         if use_dist:
             dist.barrier()
 
+    def device_idle():
+        scene.sync()              # submits what the scene still holds back, waits for its streams
+        torch.cuda.synchronize()  # and for everything else on the device
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    device_idle()
     barrier()
-    torch.cuda.synchronize()
+    device_idle()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    device_idle()
     barrier()
-    torch.cuda.synchronize()
+    device_idle()
     elapsed = time.perf_counter() - t0
     status = scene.sync()
     if use_dist:
@@ -186,18 +193,17 @@ def main():
 
     for i in range(orbit_frames):   # warm-up lap: lets the bins grow to what every angle needs
         orbit_step(i)
-    scene.sync()
-    torch.cuda.synchronize()
+    device_idle()
     barrier()
     t1 = time.perf_counter()
     for i in range(orbit_frames):
         orbit_step(i)
-    torch.cuda.synchronize()
+    device_idle()
     barrier()
     orbit_elapsed = time.perf_counter() - t1
     orbit_status = scene.sync()
     step()  # back to the headline frame for the parity check below
-    torch.cuda.synchronize()
+    device_idle()
 
     # ---- per-kernel device time of the same step, HIP events on the scene's stream ------------
     scene.profile_enable(True)

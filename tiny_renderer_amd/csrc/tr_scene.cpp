@@ -82,9 +82,20 @@ struct EventPair {
 // How many passes the setup stream may run ahead of the tile kernels: setup of pass p waits for the
 // tile kernel of pass p - LOOKAHEAD only.  With 2 the setup chain (k_setup, k_order_count,
 // k_order_place: ~35 us beside a busy machine) had to fit inside one tile kernel (~34 us) and was
-// the critical path of the frame loop; 3 gives it two.
-constexpr int LOOKAHEAD = 3;
+// the critical path of the frame loop; 3 gave it two (44.1 -> 42.4 us per frame); 5 allows batches of
+// four tile kernels per cross-stream wait (-> 39.0).  Costs LOOKAHEAD sets of bins (0.2 GB each at
+// 4096^2) -- cheap next to 288 GB.
+constexpr int LOOKAHEAD = 5;
 constexpr int SETS = LOOKAHEAD + 1;
+// Tile kernels are handed to the main stream in batches of up to BATCH passes behind ONE wait for the
+// setup stream: that wait packet, sitting between two consecutive tile kernels in the same queue,
+// costs 5.5 us (two back-to-back tile kernels are 3.8 us apart, with the wait in between 9.3).  A
+// pass that is not yet in the queue is "pending": everything that touches the main stream, waits
+// for the scene or hands control to a caller-provided stream submits the pending passes first, so
+// nothing observable changes.  BATCH <= LOOKAHEAD - 1: the setup of pass p waits for the tile kernel
+// of pass p - LOOKAHEAD, which must have been submitted by then.
+constexpr int BATCH = LOOKAHEAD - 1;
+constexpr int RING = LOOKAHEAD + 1;  // events: pass p's may be waited for until pass p + LOOKAHEAD is set up
 
 struct tr_scene {
     uint32_t width = 0, height = 0;
@@ -130,9 +141,15 @@ struct tr_scene {
     // on the main stream.  It needs only frame constants, so it overlaps the tile kernel of pass
     // p - 1: consecutive frames are in flight together, like any renderer's.
     hipStream_t setup_stream = nullptr;
-    hipEvent_t ev_setup[4] = { nullptr, nullptr, nullptr, nullptr };
-    hipEvent_t ev_tile[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_setup[RING] = {};
+    hipEvent_t ev_tile[RING] = {};
     uint64_t pass_seq = 0;
+    struct PendingTile {
+        int fs, tile_waves, kernel_id;
+        uint64_t p_seq;
+        TileArgs args;
+    };
+    std::vector<PendingTile> pending;  // passes whose setup is queued and whose tile kernel is not yet
     uint32_t tile_waves = 0;     // tr_options.tile_waves: 4, 8 or 0 = by tile count
     uint32_t bin_cap = 0;        // records per tile; grown on overflow
     uint32_t rec_pieces = 0;
@@ -243,9 +260,37 @@ int launch_status(int rc, const char *what)
     return tr::fail(TR_E_HIP, std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
 }
 
+// Puts the pending tile kernels on the main stream: one wait for the setup stream (it is in order,
+// so the newest pass's event covers the older ones), then the kernels back to back.
+int submit_pending(tr_scene *s)
+{
+    if (s->pending.empty()) return TR_OK;
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[s->pending.back().p_seq % RING], 0));
+    int status = TR_OK;
+    for (const tr_scene::PendingTile &t : s->pending) {
+        if (!s->profiling) {
+            int rc = launch_tile(t.fs, t.args, t.tile_waves, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
+            if (rc && status == TR_OK) status = launch_status(rc, "k_tile");
+        } else {
+            EventPair ep = { take_event(s), take_event(s), t.kernel_id };
+            int rc = launch_tile(t.fs, t.args, t.tile_waves, s->stream, ep.a, ep.b);
+            if (rc && status == TR_OK) status = launch_status(rc, "k_tile");
+            s->events.push_back(ep);
+            if (hipEventRecord(s->ev_tile[t.p_seq % RING], s->stream) != hipSuccess && status == TR_OK)
+                status = tr::fail(TR_E_HIP, "hipEventRecord");
+        }
+    }
+    s->pending.clear();
+    return status;
+}
+
 // Materialise a pending clear of the z / frame buffers (and winner tap).
 int flush_clear_color(tr_scene *s)
 {
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     if (!s->z_fb_cleared) return TR_OK;
     // only the rows this scene owns: in a band-sharded frame the rest belongs to other ranks
     const size_t W = s->width;
@@ -264,6 +309,10 @@ int flush_clear_color(tr_scene *s)
 int flush_clear_shadow(tr_scene *s)
 {
     if (!s->shadow_cleared) return TR_OK;
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     const size_t n = (size_t)s->width * s->height;
     Timed t(s, K_CLEAR);
     int rc = launch_fill_u32(reinterpret_cast<uint32_t *>(s->d_shadow), TR_F32_MIN_BITS, n, s->stream);
@@ -275,6 +324,10 @@ int flush_clear_shadow(tr_scene *s)
 // Gives the z buffer plain-memory meaning: tiles still behind their fast-clear flag get their f32::MIN.
 int materialize_depth(tr_scene *s)
 {
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     int rc = launch_materialize_depth(s->d_z, s->d_zclean, s->frame, s->stream);
     if (rc) return launch_status(rc, "k_materialize_depth");
     return TR_OK;
@@ -295,7 +348,7 @@ int recover_from_overflow(tr_scene *s)
     while (cap < need) cap *= 2;
     if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
     if (cap < need) cap = need;
-    if (2ull * cap * (uint64_t)s->n_tiles_full * s->rec_pieces * 16ull > (64ull << 30))
+    if ((uint64_t)LOOKAHEAD * cap * (uint64_t)s->n_tiles_full * s->rec_pieces * 16ull > (64ull << 30))
         return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 64 GiB");
     HIP_TRY(hipStreamSynchronize(s->setup_stream));
     s->bin_cap = (uint32_t)cap;
@@ -329,6 +382,10 @@ int recover_from_overflow(tr_scene *s)
 int sync_and_status(tr_scene *s)
 {
     HIP_TRY(hipSetDevice(s->device));
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
@@ -336,6 +393,8 @@ int sync_and_status(tr_scene *s)
     if (s->host_status != TR_OK) return s->host_status;
     if (err & DE_BIN_OVERFLOW) {
         int st = recover_from_overflow(s);
+        if (st != TR_OK) return st;
+        st = submit_pending(s);
         if (st != TR_OK) return st;
         HIP_TRY(hipStreamSynchronize(s->stream));
         HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
@@ -413,13 +472,13 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.err = s->d_err;
     // setup on its own stream: after the tile kernel of pass p - 2, before the tile kernel of pass p
     if (p_seq >= (uint64_t)LOOKAHEAD)
-        HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % 4], 0));
+        HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
     const uint32_t n_tiles_pass = frame.ntx * frame.nty;
     if (!s->profiling) {
         int rc = launch_setup(p.vs, sa, s->setup_stream, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
         rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, s->setup_stream, nullptr,
-                          s->ev_setup[p_seq % 4]);
+                          s->ev_setup[p_seq % RING]);
         if (rc) return launch_status(rc, "k_order");
     } else {
         // profiling: timing events on the dispatches themselves, then the pipeline's event separately
@@ -431,10 +490,8 @@ int run_pass(tr_scene *s, const PassDesc &p)
         rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, s->setup_stream, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
         s->events.push_back(eo);
-        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % 4], s->setup_stream));
+        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], s->setup_stream));
     }
-    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[p_seq % 4], 0));
-
     TileArgs ta;
     ta.bins = bins;
     ta.bin_cap = s->bin_cap;
@@ -459,18 +516,18 @@ int run_pass(tr_scene *s, const PassDesc &p)
     // slower beyond (more total work).  Measured on diablo (k_tile, us, 4 / 8 / 16 waves): 800^2
     // 97 / 65 / 46, 1024^2 76 / 53 / 37, 2048^2 42 / 31 / 27, 4096^2 36 / 44 / 74.
     const int tile_waves = s->tile_waves ? (int)s->tile_waves : n_tiles_pass <= 2048u ? 16 : n_tiles_pass <= 4096u ? 8 : 4;
-    if (!s->profiling) {
-        int rc = launch_tile(p.fs, ta, tile_waves, s->stream, nullptr, s->ev_tile[p_seq % 4]);
-        if (rc) return launch_status(rc, "k_tile");
-    } else {
-        EventPair ep = { take_event(s), take_event(s), depth_pass ? K_TILE_DEPTH : K_TILE };
-        int rc = launch_tile(p.fs, ta, tile_waves, s->stream, ep.a, ep.b);
-        if (rc) return launch_status(rc, "k_tile");
-        s->events.push_back(ep);
-        HIP_TRY(hipEventRecord(s->ev_tile[p_seq % 4], s->stream));
-    }
+    tr_scene::PendingTile pt;
+    pt.fs = p.fs;
+    pt.tile_waves = tile_waves;
+    pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
+    pt.p_seq = p_seq;
+    pt.args = ta;
+    s->pending.push_back(pt);
     bs.seq++;
     s->pass_seq++;
+    // a caller's stream must hold the frame when render() returns (its next operation may consume
+    // it); on the library's own stream up to BATCH passes wait for company
+    if ((int)s->pending.size() >= BATCH || !s->own_stream) return submit_pending(s);
     return TR_OK;
 }
 
@@ -501,6 +558,7 @@ void destroy(tr_scene *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    (void)submit_pending(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (const EventPair &ep : s->events) {
         (void)hipEventDestroy(ep.a);
@@ -510,7 +568,7 @@ void destroy(tr_scene *s)
     dev_free(s->d_tri);
     for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
     if (s->setup_stream) (void)hipStreamSynchronize(s->setup_stream);
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < RING; k++) {
         if (s->ev_setup[k]) (void)hipEventDestroy(s->ev_setup[k]);
         if (s->ev_tile[k]) (void)hipEventDestroy(s->ev_tile[k]);
     }
@@ -650,7 +708,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     for (int k = 0; k < LOOKAHEAD; k++)
         if ((st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
     HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < RING; k++) {
         HIP_TRY(hipEventCreateWithFlags(&s->ev_setup[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_tile[k], hipEventDisableTiming));
     }
@@ -697,6 +755,10 @@ int depth_view(tr_scene *s, const float *src, uint8_t *rgb)
     if (!s->d_view) {
         int st = dev_alloc(&s->d_view, npx * 3);
         if (st) return st;
+    }
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
     }
     int rc = launch_depth_view(src, s->d_view, s->width, s->height, s->stream);
     if (rc) return launch_status(rc, "k_depth_view");
@@ -821,6 +883,10 @@ int tr_scene_set_stream(tr_scene *s, void *hip_stream)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
     HIP_TRY(hipSetDevice(s->device));
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->own_stream) (void)hipStreamDestroy(s->stream);
     s->own_stream = false;
@@ -847,6 +913,8 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
     int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    st = submit_pending(s);
     if (st != TR_OK) return st;
     // same stream as the tile kernels: after the frame, before the next one overwrites it
     HIP_TRY(hipMemcpyAsync(rgb, s->d_fb, (size_t)s->width * s->height * 3, hipMemcpyDeviceToHost, s->stream));
@@ -919,6 +987,10 @@ int tr_scene_debug_tile_stamps(tr_scene *s, uint64_t *out, uint32_t cap_tiles)
     if (!s->d_stamps) return tr::fail(TR_E_INVALID, "scene was created without TR_OPT_TILE_STAMPS");
     if (cap_tiles < s->n_tiles) return tr::fail(TR_E_INVALID, "buffer too small");
     HIP_TRY(hipSetDevice(s->device));
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(out, s->d_stamps, (size_t)s->n_tiles * 64, hipMemcpyDeviceToHost));
     return (int)s->n_tiles;
@@ -928,6 +1000,10 @@ int tr_scene_profile_enable(tr_scene *s, int on)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
     HIP_TRY(hipSetDevice(s->device));
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     drain_events(s);
     s->profiling = on != 0;
@@ -942,6 +1018,10 @@ int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap)
 {
     if (!s || !out || cap <= 0) return tr::fail(TR_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(s->device));
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     drain_events(s);
     int n = 0;
