@@ -13,7 +13,7 @@ for _ in range(5):
     s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()
 s.sync()
 st = s.debug_tile_stamps().astype(np.int64)
-t0 = st[st[:, 2] > 0, 0].min()  # sweep blocks leave no stamp
+t0 = st[st[:, 2] > 0, 0].min()  # workgroups of empty tiles leave no stamp
 start, end, n = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, st[:, 2]   # us
 dur = end - start
 busy = n > 0

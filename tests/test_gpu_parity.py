@@ -371,8 +371,7 @@ def test_device_math_selftest(built):
 
 @pytest.mark.parametrize("pipe", ["phong", "occlusion"])
 def test_every_tile_heavy(synthetic, pipe):
-    """All tiles busy and heavy: heavy list + busy list together are longer than the tile count
-    (a tile sits on both), which must not drop entries."""
+    """Every tile holds many polygons: the work list consists of its heaviest buckets only."""
     mesh, texs = synthetic
     gpu, cpu = render_pair(256, 64, mesh, texs, pipe, 0.0, 0.0)
     assert_parity(gpu, cpu, pipe)

@@ -2,15 +2,18 @@
 //
 // The reference (src/scene.rs:151-268) is one serial loop nest: pass x polygon x bbox-x x
 // bbox-y, depth-testing and shading each covered pixel in polygon order.  Here a render pass is
-// two kernels:
+// four kernels:
 //
-//   k_setup   one lane per polygon: vertex closure, clamped bounding box; then the wavefront
-//             spreads its (polygon, tile) pairs over all 64 lanes and appends the polygon's
-//             complete record to the fixed-capacity bin of every tile it touches
-//   k_tile    one 256-thread workgroup per 128x16 screen tile: the bin is copied into LDS in one
-//             coalesced sweep, each wave resolves coverage + depth for its 32x16 quadrant against
-//             LDS keys, then the survivors are shaded from the LDS records and depth and colour
-//             are streamed out once, as whole cache lines
+//   k_setup        one lane per polygon: vertex closure, clamped bounding box; then the wavefront
+//                  spreads its (polygon, tile) pairs over all 64 lanes and appends the polygon's
+//                  complete record to the fixed-capacity bin of every tile it touches
+//   k_order_count, k_order_place
+//                  one thread per tile: the tile kernel's work list, tiles sorted by polygon count
+//   k_tile         one workgroup (4, 8 or 16 waves) per 128x16 screen tile, heaviest tiles first:
+//                  the bin is copied into LDS in one coalesced pass, each wave resolves coverage +
+//                  depth for its column of the tile against LDS keys, then the survivors are shaded
+//                  from the LDS records and depth and colour are streamed out once, as whole cache
+//                  lines; tiles without polygons only stream their cleared colour
 //
 // Equivalence with the serial loop: `z <= zbuf -> reject` in polygon order means the surviving
 // fragment of a pixel is the one with the largest z, ties going to the lowest polygon index, and

@@ -121,25 +121,23 @@ struct tr_scene {
     // device allocations
     float *d_tri = nullptr;
     uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
-    // Per-tile polygon counters, busy-tile lists and their lengths, double buffered: a pass fills and
-    // reads set `cur`, its tile kernel zeroes the other set for the next pass of the same kind.
-    // Colour passes (the scene's band) and depth passes (always the whole frame) have different
-    // tile grids, hence a state each.
+    // Per-tile polygon counters (followed by k_order's 16 words).  Colour passes (the scene's band)
+    // and depth passes (always the whole frame) have different tile grids, hence a state each.
     // SETS sets: the tile kernel of pass q zeroes set (q + SETS - 1) % SETS, which no pass before
-    // q + SETS - 1 touches; meanwhile the setup kernels of passes q + 1 and q + 2 (running ahead on
-    // the setup stream, see LOOKAHEAD) fill sets (q + 1) % SETS and (q + 2) % SETS.
+    // q + SETS - 1 touches; meanwhile the setup kernels of passes q + 1 .. q + LOOKAHEAD - 1 (running
+    // ahead on the setup stream) fill their own sets.
     struct BinState {
         uint32_t *count[SETS] = {};
         uint64_t seq = 0;           // passes of this kind issued so far
     } bin_color, bin_depth;
     // Record bins and work lists, LOOKAHEAD-buffered by global pass number: pass p's setup fills
-    // bins[p % LOOKAHEAD] while the tile kernels of passes p - 1 and p - 2 may still be reading theirs.
+    // bins[p % LOOKAHEAD] while the tile kernels of the passes before it may still be reading theirs.
     WorkItem *d_order[LOOKAHEAD] = {};  // the tile kernel's work list (k_order)
     Piece *d_bins[LOOKAHEAD] = {};      // each n_tiles_full x bin_cap records of rec_pieces x 16 B
-    // Pass pipelining: k_setup of pass p runs on `setup_stream`, ordered after the tile kernel of
-    // pass p - 2 (which frees its bins and zeroed its counters) and before the tile kernel of pass p
-    // on the main stream.  It needs only frame constants, so it overlaps the tile kernel of pass
-    // p - 1: consecutive frames are in flight together, like any renderer's.
+    // Pass pipelining: k_setup and k_order_* of pass p run on `setup_stream`, ordered after the tile
+    // kernel of pass p - LOOKAHEAD (which freed its bins and zeroed its counters) and before the tile
+    // kernel of pass p on the main stream.  They need only frame constants, so they overlap the tile
+    // kernels of earlier passes: consecutive frames are in flight together, like any renderer's.
     hipStream_t setup_stream = nullptr;
     hipEvent_t ev_setup[RING] = {};
     hipEvent_t ev_tile[RING] = {};
@@ -470,7 +468,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.rec_pieces = s->rec_pieces;
     sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
-    // setup on its own stream: after the tile kernel of pass p - 2, before the tile kernel of pass p
+    // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p
     if (p_seq >= (uint64_t)LOOKAHEAD)
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
     const uint32_t n_tiles_pass = frame.ntx * frame.nty;

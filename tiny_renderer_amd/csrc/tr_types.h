@@ -91,8 +91,6 @@ constexpr int REC_PIECES_LARGE = 9;  // 144 B
 // Records a tile keeps resident in LDS (8 KiB worth = 85 / 56 records); larger bins take the
 // chunked path.  With the 16 KiB of keys a workgroup stays under 25 KiB: six fit in a CU's LDS.
 constexpr int LDS_REC_BYTES = 8192;
-// A tile whose bin reaches this many polygons is "heavy": the tile kernel starts heavy tiles
-// first (longest-processing-time-first packing of the launch).
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {
