@@ -248,6 +248,28 @@ def test_depth_views(small_synthetic):
     assert np.array_equal(gpu.get_shadow_buffer(), cpu.get_shadow_buffer())
 
 
+def test_instanced_grid_specular(synthetic):
+    """BASELINE.json configs[4] in small: the n x n instanced grid (SURVEY 8d defines the instancing),
+    -s specular, many small polygons per tile; whole frame and two of its row bands."""
+    import tiny_renderer_amd as T
+    mesh, texs = synthetic
+    grid = T.instanced_grid(mesh, 4)
+    assert grid["idx"].shape[0] == 16 * mesh["idx"].shape[0]
+    W, Hh = 2048, 1024
+    gpu, cpu = render_pair(W, Hh, grid, texs, "specular", 0.0, 0.0)
+    assert_parity(gpu, cpu, "specular")
+    ref = cpu.get_frame_buffer()
+    for band in ((0, 256), (512, 1024)):
+        b = T.Scene(W, Hh, grid, texs, "specular", band_rows=band)
+        b.clear()
+        b.set_light_direction(H.light(0.0))
+        b.set_camera(*H.camera(0.0))
+        b.render()
+        d = np.abs(b.get_frame_buffer()[band[0]:band[1]].astype(np.int32) - ref[band[0]:band[1]].astype(np.int32))
+        assert d.max() <= 1  # tolerance: 1 LSB (powf)
+        b.close()
+
+
 def test_determinism(synthetic):
     import tiny_renderer_amd as T
     mesh, texs = synthetic
