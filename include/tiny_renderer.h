@@ -147,6 +147,11 @@ int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap);
 int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t n, uint32_t *out_u32,
                             int32_t *out_i32, uint32_t *out_u8, float *out_div, float *out_div_ref);
 
+/* 1 when this build's specular pipeline (shader.rs:472-543, the only one that calls powf) returns
+ * the host C library's powf bit for bit -- the library was built against a glibc whose powf
+ * tables it could read (csrc/gen_powf_tables.py); 0: the device library's powf, within 1 ulp. */
+int tr_specular_exact(void);
+
 /* shader.rs:97-112 registry */
 int tr_pipeline_count(void);
 const char *tr_pipeline_name(int i);

@@ -260,5 +260,12 @@ extern "C" int tr_emul_covers(const int32_t raster[6], int32_t px, int32_t py, f
 
 extern "C" uint32_t tr_emul_depth_order_key(float z) { return depth_order_key(z); }
 
+// the specular closure's powf (tr_powf.h) for n argument pairs; returns TR_POWF_EXACT
+extern "C" int tr_emul_powf(const float *x, const float *y, float *out, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = tr_powf(x[i], y[i]);
+    return TR_POWF_EXACT;
+}
+
 // x / d through the shared-reciprocal division of tr_math.h
 extern "C" float tr_emul_div_by(float x, float d) { return div_by(x, recip_of(d)); }

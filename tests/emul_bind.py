@@ -22,6 +22,8 @@ def lib():
         L.tr_emul_depth_order_key.argtypes = [C.c_float]
         L.tr_emul_div_by.restype = C.c_float
         L.tr_emul_div_by.argtypes = [C.c_float, C.c_float]
+        L.tr_emul_powf.restype = C.c_int
+        L.tr_emul_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _lib = L
     return _lib
 

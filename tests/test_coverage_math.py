@@ -82,3 +82,28 @@ def test_depth_order_key():
     assert keys[5] == keys[6]                       # -0.0 == +0.0 for `z <= zbuf`
     ks = keys[:5] + keys[6:]
     assert all(a < b for a, b in zip(ks, ks[1:]))
+
+
+def test_powf_reproduces_the_host_libm():
+    """tr_powf.h restates glibc's powf with the constants read out of the installed libm
+    (csrc/gen_powf_tables.py); the specular closure uses it so that the device returns what the
+    reference's f32::powf (= the platform powf) returns.  Domain of the closure: base in [0, 1]
+    (max(r.z, 0) of a unit vector), exponent 0..255; special values on top."""
+    L = E.lib()
+    libm = C.CDLL("libm.so.6")
+    libm.powf.restype = C.c_float
+    libm.powf.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(5)
+    n = 400000
+    x = np.concatenate([rng.random(n), 1.0 - rng.random(n) * 2.0 ** -rng.integers(1, 24, n), 2.0 ** -rng.uniform(0, 149, n),
+                        [0.0, 1.0, 1.0000001, 1e-45, 1.1754942e-38, 0.5, np.inf, np.nan, 2.0, -0.0]]).astype(np.float32)
+    y = np.concatenate([rng.integers(0, 256, 3 * n), [0, 0, 255, 7, 255, 0, 3, 2, 200, 5]]).astype(np.float32)
+    out = np.zeros(x.size, np.float32)
+    exact = L.tr_emul_powf(x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size)
+    if not exact:
+        import pytest
+        pytest.skip("the installed libm's powf tables were not recognised: the device library's powf is used (1 ulp)")
+    ref = np.array([libm.powf(float(a), float(b)) for a, b in zip(x[::7], y[::7])], np.float32)
+    got = out[::7]
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), list(zip(x[::7][~same][:5], y[::7][~same][:5], got[~same][:5], ref[~same][:5]))

@@ -1,6 +1,7 @@
 """Committed fingerprints (tests/golden/oracle_hashes.json, made by tests/golden/make_golden.py):
 the oracle must keep reproducing them (CPU), and the GPU must produce frames with the same
-fingerprints (GPU; specular's RGB is compared with its 1-LSB tolerance instead)."""
+fingerprints (GPU; specular's RGB only when the library reproduces the host libm's powf,
+tr_specular_exact(): with the device library's powf it is within 1 LSB and checked elsewhere)."""
 import json
 import os
 
@@ -46,6 +47,6 @@ def test_gpu_matches_fingerprints(built, name, W, Hh, ca, la, pipe):
     assert G.sha(s.read_winner_u32()) == gold["winner"]
     if "shadow" in gold:
         assert G.sha(s.read_shadow_f32().view(np.uint32)) == gold["shadow"]
-    if pipe != "specular":
+    if pipe != "specular" or T.load_library().tr_specular_exact():
         assert G.sha(fb) == gold["fb"]
     s.close()

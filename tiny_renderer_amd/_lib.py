@@ -95,6 +95,7 @@ SYMBOLS = {
     "tr_save_tga_rgb8": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "tr_last_error": (C.c_char_p, []),
     "tr_abi_version": (C.c_int, []),
+    "tr_specular_exact": (C.c_int, []),
 }
 
 

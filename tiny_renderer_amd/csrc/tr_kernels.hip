@@ -928,6 +928,8 @@ int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u3
     return 0;
 }
 
+int specular_is_exact() { return TR_POWF_EXACT; }
+
 int launch_depth_view(const float *src, uint8_t *dst, uint32_t W, uint32_t H, hipStream_t st)
 {
     const size_t n = (size_t)W * H;

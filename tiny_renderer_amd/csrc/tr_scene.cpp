@@ -772,6 +772,8 @@ extern "C" {
 
 int tr_abi_version(void) { return TR_ABI_VERSION; }
 
+int tr_specular_exact(void) { return tr::specular_is_exact(); }
+
 const char *tr_last_error(void) { return tr::g_last_error.c_str(); }
 
 int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t n, uint32_t *out_u32,

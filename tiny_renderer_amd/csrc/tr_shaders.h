@@ -9,6 +9,7 @@
 
 #include "tr_math.h"
 #include "tr_pk.h"
+#include "tr_powf.h"
 #include "tr_types.h"
 
 namespace tr {
@@ -393,7 +394,7 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
         vec3 refl = normalize3(sub3(make3(2.0f * a.x, 2.0f * a.y, 2.0f * a.z), tl));
         float diff = dot3(tl, tn);
         float e = (float)(fetch_texel(tex, 3, 3, uu, vv, err) & 0xFFu);
-        float spec = 0.6f * powf(fmaxf(refl.z, 0.0f), e);
+        float spec = 0.6f * tr_powf(fmaxf(refl.z, 0.0f), e);  // the host libm's powf, bit for bit (tr_powf.h)
         float k = diff + spec;
         return pack_rgb(f32_to_u8(fminf(k * (float)(c & 0xFFu), 255.0f)),
                         f32_to_u8(fminf(k * (float)((c >> 8) & 0xFFu), 255.0f)),
