@@ -429,3 +429,62 @@ def test_frames_in_flight(small_synthetic, pipe):
         cpu.set_camera(*H.camera(0.37 * (burst - 1) + burst))
         assert cpu.render() == 0
         assert_parity(gpu, cpu, pipe)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_api_sequences(small_synthetic, seed):
+    """Random interleavings of the whole API surface (clear / setters / render / every getter / the
+    asynchronous read-back / sync) against the oracle driven by the same calls: renders are held back
+    and submitted in batches, clears are lazy, z lives behind per-tile flags -- none of which may show."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    rng = np.random.default_rng(700 + seed)
+    # (occlusion is left out: a random light can hit the antiparallel case in which the reference panics)
+    pipe = ["phong", "shadow", "default", "normal_map", "darboux", "specular"][seed % 6]
+    W, Hh = [(320, 200), (1100, 700), (640, 64)][seed % 3]
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_waves=[0, 4, 8, 16][seed % 4])
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    pinned = gpu.pinned_frame()
+    pending_async = False
+    for step in range(45):
+        op = rng.choice(["clear", "camera", "light", "render", "render", "render", "frame", "z", "zview", "shadow",
+                         "winner", "async", "sync"])
+        if op == "clear":
+            gpu.clear(); cpu.clear()
+        elif op == "camera":
+            a = float(rng.uniform(-3.0, 3.0))
+            off = [float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.3, 0.3))]
+            frm = [float(np.sin(np.float32(a))) + off[0], off[1], float(np.cos(np.float32(a)))]
+            for s in (gpu, cpu):
+                s.set_camera(frm, [off[0], off[1], 0.0], [0.0, 1.0, 0.0])
+        elif op == "light":
+            v = H.light(float(rng.uniform(-2.0, 2.0)))
+            gpu.set_light_direction(v); cpu.set_light_direction(v)
+        elif op == "render":
+            gpu.render()
+            assert cpu.render() == 0
+        elif op == "frame":
+            assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer()), (step, op)
+        elif op == "z":
+            assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32)), (step, op)
+        elif op == "zview":
+            assert np.array_equal(gpu.get_z_buffer(), cpu.get_z_buffer()), (step, op)
+        elif op == "shadow":
+            assert np.array_equal(gpu.read_shadow_f32().view(np.uint32), cpu.shadow_f32().view(np.uint32)), (step, op)
+        elif op == "winner":
+            assert np.array_equal(gpu.read_winner_u32(), cpu.winner_u32()), (step, op)
+        elif op == "async":
+            gpu.get_frame_buffer_async(pinned)
+            expect = cpu.get_frame_buffer()
+            pending_async = True
+        if op == "sync" or (pending_async and op in ("render", "clear")):
+            if pending_async:   # a later render may not disturb a queued read-back
+                assert gpu.sync() == 0
+                assert np.array_equal(pinned, expect), (step, "async")
+                pending_async = False
+            elif op == "sync":
+                assert gpu.sync() == 0
+    assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer())
+    assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
+    gpu.close()
