@@ -327,7 +327,7 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 }
 
 template <int FS, int TILE_WAVES>
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(FS == FS_DARBOUX ? 5 : 6, FS == FS_DARBOUX ? 5 : 6))) void k_tile(TileArgs a)
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(FS == FS_DARBOUX ? 5 : TILE_WAVES == 16 ? 8 : 6, FS == FS_DARBOUX ? 5 : TILE_WAVES == 16 ? 8 : 6))) void k_tile(TileArgs a)
 {
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
