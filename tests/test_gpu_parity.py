@@ -348,6 +348,20 @@ def test_full_size_properties_4096(synthetic):
     assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[1], masks[2])
 
 
+@pytest.mark.parametrize("cfg", [("phong", 4096, 1), ("darboux", 4096, 1), ("shadow", 4096, 1), ("specular", 8192, 8)])
+def test_baseline_configs_at_full_size(diablo, cfg):
+    """BASELINE.json configs[2..4] and the metric's own workload (diablo / phong / 4096^2) compared with
+    the oracle's complete frame, z and winner at full size (the oracle needs 0.1-1.7 s per frame)."""
+    pipe, size, grid = cfg
+    import tiny_renderer_amd as T
+    mesh, texs = diablo
+    if grid > 1:
+        mesh = T.instanced_grid(mesh, grid)
+    gpu, cpu = render_pair(size, size, mesh, texs, pipe, 0.0, 0.0)
+    assert_parity(gpu, cpu, pipe)
+    gpu.close()
+
+
 @pytest.mark.parametrize("pipe", ["phong", "shadow"])
 def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
     """More polygons per tile than the bins hold: the library grows the bins and renders the
