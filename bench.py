@@ -251,8 +251,12 @@ def main():
             cpu.clear()
             t_clear = time.perf_counter() - t1
             per_frame = spent / frames + t_clear
+            try:
+                model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:
+                model = "unknown"
             cpu_baseline = {"value": round(n_shaded / per_frame / 1e6, 3), "unit": "Mpixels/s shaded",
-                            "cores": 1, "kind": "port",
+                            "cores": 1, "kind": "port", "host_cpu": model, "host_cores_available": os.cpu_count(),
                             "sample": "%d frames of the same workload (clear+render), CPU oracle "
                                       "(C restatement of the reference, single-threaded like it), "
                                       "%.3f s/frame" % (frames, per_frame)}
