@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle parity sweep (not part of the test suite): `python scripts/parity_sweep.py [n_seeds]`.
 Polygon soups with exact depth ties and far-away / sliver polygons, five frame shapes, every tile
-layout, five pipelines; prints every mismatch.  Round 1: 240 seeds, 0 mismatches."""
+layout, five pipelines; prints every mismatch.  Round 1: 2 494 cases (2 500 seeds), 0 mismatches."""
 import sys; sys.path.insert(0, '.')
 import numpy as np, time
 import tiny_renderer_amd as T
