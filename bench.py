@@ -75,8 +75,8 @@ def algorithmic_bytes(W, H, pipe, stats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)  # 80 ms at N=1: the 5-frame pipeline's fill and drain stay below 1 %
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--pipeline", default="phong")
     ap.add_argument("--model", default="diablo")
@@ -158,8 +158,8 @@ def main():
             dist.barrier()
 
     def device_idle():
-        scene.sync()              # submits what the scene still holds back, waits for its streams
-        torch.cuda.synchronize()  # and for everything else on the device
+        scene.flush()             # the scene may hold renders back to batch them: hand them over,
+        torch.cuda.synchronize()  # then wait for every stream of the device
 
     for _ in range(args.warmup):
         step()

@@ -123,6 +123,8 @@ void tr_host_free(void *p);
 
 /* Device-resident access for callers that keep the frame on the GPU. */
 int tr_scene_sync(tr_scene *s);                 /* wait for queued work; returns frame status */
+int tr_scene_flush(tr_scene *s);                /* hand every render issued so far to the device (the library
+                                                   may hold a few back to batch them); does not wait */
 void *tr_scene_frame_buffer_device(tr_scene *s); /* 3*W*H bytes, row 0 = top */
 int tr_scene_set_stream(tr_scene *s, void *hip_stream);
 

@@ -78,6 +78,7 @@ SYMBOLS = {
     "tr_scene_read_shadow_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_read_winner_u32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_sync": (C.c_int, [C.c_void_p]),
+    "tr_scene_flush": (C.c_int, [C.c_void_p]),
     "tr_scene_frame_buffer_device": (C.c_void_p, [C.c_void_p]),
     "tr_scene_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_debug_tile_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),

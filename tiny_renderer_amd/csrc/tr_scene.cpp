@@ -871,6 +871,13 @@ int tr_scene_render(tr_scene *s)
     return render_frame(s);
 }
 
+int tr_scene_flush(tr_scene *s)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    return submit_pending(s);
+}
+
 int tr_scene_sync(tr_scene *s)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");

@@ -147,6 +147,10 @@ class Scene:
     def sync(self):
         return check(load_library().tr_scene_sync(self._h))
 
+    def flush(self):
+        """Hand every render issued so far to the device without waiting (renders may be held back in batches)."""
+        return check(load_library().tr_scene_flush(self._h))
+
     def frame_buffer_device(self):
         return load_library().tr_scene_frame_buffer_device(self._h)
 
