@@ -10,11 +10,11 @@ rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 
 echo "== bench"
-python3 bench.py --steps 200 --warmup 20 > "$out/bench_4096_phong.log" 2> "$out/bench_4096_phong.err" || exit 1
+python3 bench.py > "$out/bench_4096_phong.log" 2> "$out/bench_4096_phong.err" || exit 1
 tail -n 1 "$out/bench_4096_phong.log"
 
 echo "== kernel trace"
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu \
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- python3 bench.py --no-cpu \
     > "$out/bench_under_rocprof.log" 2> "$out/trace.err" || exit 1
 tail -n 1 "$out/bench_under_rocprof.log"
 
