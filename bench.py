@@ -6,7 +6,7 @@
 A "step" is one frame through the reference's per-frame protocol (app.rs:170,208-213):
 clear -> set_light_direction -> set_camera -> render, with the finished frame left in HBM
 (`get_frame_buffer`'s vertical flip is folded into the render's store address; no host
-readback inside the timed region).
+readback inside the timed region; the readback-inclusive rate is reported beside it).
 
 Workload at N=1: diablo.obj, -s phong, 4096x4096 -- the configuration the metric
 "Mpixels/s shaded (z-test + Phong) at 4096x4096" is quoted on.  `value` =
@@ -14,17 +14,24 @@ N_shaded * K / t / 1e6 where N_shaded is the number of fragments the reference's
 shades (z-accepts), counted by the CPU oracle on the same frame -- the GPU
 shades only the survivors but is credited with the reference's count, never more.
 
-N>1: the frame is sharded by screen rows over the ranks (one process per GPU) and the final
-framebuffer is all-gathered over RCCL/xGMI every frame (north_star); total work is fixed, so
-"scaling" is "strong".
+N>1: one process per GPU.  `python bench.py --gpus N` without a launcher starts the N rank
+processes itself (torch.distributed.run, before anything in this process touches a GPU) and
+relays rank 0's line; under torchrun it joins the group it finds and refuses to run if the
+group's size is not N.  The frame is sharded by screen rows (tr_band_rows) over the ranks and the
+final framebuffer is all-gathered over RCCL/xGMI every frame (north_star); frames are
+double-buffered so that the gather of frame f runs on a second stream under the render of
+frame f+1.  Total work is fixed, so "scaling" is "strong".
 
 The reference's assets are used when present ($TR_ASSETS, assets/_ref copied by
 __graft_entry__.build(), or /root/reference/assets); otherwise a procedural sphere with the same
 polygon count stands in and `config.workload` says so.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -72,10 +79,38 @@ def algorithmic_bytes(W, H, pipe, stats):
     return out
 
 
+def source_fingerprint():
+    """sha256 over the sources the device code is built from.  profiles/pmc_traffic.json records the
+    fingerprint of the build that was profiled (scripts/summarise_profiles.py); a counter value
+    measured on other code is not reported (the GPU box has no .git to ask for a commit)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "tiny_renderer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks, one per GPU, from this
+    process -- which has not imported torch, let alone touched a GPU -- and pass rank 0's JSON on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)  # 80 ms at N=1: the 5-frame pipeline's fill and drain stay below 1 %
+    ap.add_argument("--steps", type=int, default=2000)  # 70 ms at N=1: the frame pipeline's fill and drain stay below 1 %
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--pipeline", default="phong")
@@ -83,28 +118,51 @@ def main():
     ap.add_argument("--grid", type=int, default=1, help="n x n instancing (configs[4] uses 8)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the orbit / latency / read-back legs (profiling runs)")
+    ap.add_argument("--exchange", choices=("rccl", "peer"), default=os.environ.get("TR_BENCH_EXCHANGE", "rccl"),
+                    help="N>1: how the bands travel: torch.distributed all_gather (RCCL) or the library's "
+                         "peer-to-peer band copies (tr_exchange_*)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the render stream (no double buffering)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args, sys.argv[1:])  # does not return
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d: refusing to label a %d-rank run as %d GPUs"
+                         % (args.gpus, world, world, args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    # TR_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, band scene, in-place
-    # all-gather) with a single rank: a rehearsal of the RCCL plumbing on a one-GPU box.
+    if world > 1 and torch.cuda.device_count() < world and os.environ.get("TR_BENCH_SHARE_GPU") != "1":
+        raise SystemExit("%d ranks but %d GPUs visible" % (world, torch.cuda.device_count()))
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    # TR_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, band scene, double-buffered
+    # gather on a second stream) with a single rank: a rehearsal of the plumbing on a one-GPU box.
     use_dist = world > 1 or os.environ.get("TR_BENCH_FORCE_DIST") == "1"
+    group_ranks = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = "nccl" if args.exchange == "rccl" else "gloo"  # the peer exchange only needs a rendezvous
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+        group_ranks = dist.get_world_size()
+        if group_ranks != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus says %d" % (group_ranks, args.gpus))
 
     import tiny_renderer_amd as T
 
@@ -127,31 +185,80 @@ def main():
     cam, lt = camera(0.0), light(0.0)  # the state of the reference's first frame (app.rs:158-159)
 
     # ---- the scene on this rank -------------------------------------------------------------
-    # N > 1: the scene renders on torch's stream so that the all-gather is ordered behind it.
-    # N = 1: the library's own stream (its frame pipelining hands tile kernels over in batches there).
-    stream = torch.cuda.current_stream().cuda_stream if use_dist else None
-    fb = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
+    # N = 1: the library's own stream (its frame pipelining hands tile kernels over in batches there)
+    #        and one frame buffer.
+    # N > 1: the scene renders on a real torch side stream (never the null stream: tr_options.stream
+    #        = NULL means a library-owned stream, and a collective on torch's current stream would not
+    #        be ordered behind it) into one of two frame tensors; the exchange of frame f runs on a
+    #        second stream, ordered by events, under the render of frame f + 1.
+    n_buf = 1 if (not use_dist or args.no_overlap) else 2
+    fbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    render_stream = comm_stream = None
     band = None
     if use_dist:
-        rows = [(r * H) // world for r in range(world + 1)]
-        band = (rows[rank], rows[rank + 1])
-        if len({rows[r + 1] - rows[r] for r in range(world)}) != 1:
-            raise SystemExit("frame height must divide by the number of GPUs")
-    scene = T.Scene(W, H, mesh, texs, pipe, device=local_rank, stream=stream,
-                    frame_buffer_device=fb.data_ptr(), band_rows=band)
-    chunk = None
+        render_stream = torch.cuda.Stream()
+        comm_stream = render_stream if args.no_overlap else torch.cuda.Stream()
+        if render_stream.cuda_stream == 0:
+            raise SystemExit("the render stream must not be the null stream")
+        band = T.band_rows(H, world, rank)
+        if len({T.band_rows(H, world, r)[1] - T.band_rows(H, world, r)[0] for r in range(world)}) != 1:
+            raise SystemExit("frame height must divide by the number of GPUs (in-place all-gather)")
+    torch.cuda.synchronize()
+    scene = T.Scene(W, H, mesh, texs, pipe, device=device_index,
+                    stream=render_stream.cuda_stream if use_dist else None,
+                    frame_buffer_device=fbs[0].data_ptr(), band_rows=band)
+    chunks = None
+    exchange = None
     if use_dist:
         n = (band[1] - band[0]) * W * 3
-        chunk = fb[rank * n:(rank + 1) * n]
+        chunks = [fb[rank * n:(rank + 1) * n] for fb in fbs]
+        if args.exchange == "peer":
+            exchange = T.PeerExchange(fbs, band, W, H, rank, world, dist)
+    rendered = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
+    gathered = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
+    gather_started = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
+    render_started = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
+    frame_no = [0]
+    timing = {"on": False, "render_ms": [], "gather_ms": [], "timed": [False] * n_buf}
 
-    def step():
-        scene.clear()
-        scene.set_light_direction(lt)
-        scene.set_camera(*cam)
-        scene.render()
-        if use_dist:
-            dist.all_gather_into_tensor(fb, chunk)
+    def collect_times(b):
+        # per-rank device times of the frame that last used slot b (its events have completed or are
+        # about to: the render stream is made to wait for `gathered[b]` anyway)
+        if timing["timed"][b]:
+            gathered[b].synchronize()
+            timing["render_ms"].append(render_started[b].elapsed_time(rendered[b]))
+            timing["gather_ms"].append(gather_started[b].elapsed_time(gathered[b]))
+            timing["timed"][b] = False
+
+    def step(cam_now=cam):
+        if not use_dist:
+            scene.clear()
+            scene.set_light_direction(lt)
+            scene.set_camera(*cam_now)
+            scene.render()
+            return
+        b = frame_no[0] % n_buf
+        frame_no[0] += 1
+        collect_times(b)
+        with torch.cuda.stream(render_stream):
+            if frame_no[0] > n_buf:
+                render_stream.wait_event(gathered[b])  # the exchange of the frame that used this buffer is done
+            render_started[b].record(render_stream)
+            scene.set_frame_buffer_device(fbs[b].data_ptr())
+            scene.clear()
+            scene.set_light_direction(lt)
+            scene.set_camera(*cam_now)
+            scene.render()  # a caller's stream receives the frame's kernels before render() returns
+            rendered[b].record(render_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(rendered[b])
+            gather_started[b].record(comm_stream)
+            if exchange is not None:
+                exchange.all_gather(b, comm_stream)
+            else:
+                dist.all_gather_into_tensor(fbs[b], chunks[b])
+            gathered[b].record(comm_stream)
+        timing["timed"][b] = timing["on"]
 
     def barrier():
         if use_dist:
@@ -174,43 +281,98 @@ def main():
     device_idle()
     elapsed = time.perf_counter() - t0
     status = scene.sync()
+    last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    extras = not args.no_extras
     # ---- metric 2: frames/s with the camera orbiting by 2*pi/200 per frame ---------
     # (deterministic stand-in for the reference's keyboard orbit, app.rs:173-200); not `value`.
-    orbit_frames = 200
+    orbit_frames, orbit_elapsed, orbit_status = 200, None, None
+    if extras:
+        for lap in range(3):   # warm-up laps: the bins grow to what every angle needs (a frame whose bins
+            try:               # overflowed on a caller's stream is reported, not silently repaired)
+                for i in range(orbit_frames):
+                    step(camera(2.0 * np.pi * i / orbit_frames))
+                device_idle()
+                scene.sync()
+                break
+            except T.TinyRendererError as e:
+                if e.code != -9:
+                    raise
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(orbit_frames):
+            step(camera(2.0 * np.pi * i / orbit_frames))
+        device_idle()
+        barrier()
+        orbit_elapsed = time.perf_counter() - t1
+        try:
+            orbit_status = scene.sync()
+        except T.TinyRendererError as e:
+            orbit_status = e.code
 
-    def orbit_step(i):
-        scene.clear()
-        scene.set_light_direction(lt)
-        scene.set_camera(*camera(2.0 * np.pi * i / orbit_frames))
-        scene.render()
-        if use_dist:
-            dist.all_gather_into_tensor(fb, chunk)
+    # ---- single-frame latency: clear -> render -> sync with nothing else in flight -----------------
+    latency_us = None
+    if extras:
+        lat = []
+        for _ in range(30):
+            device_idle()
+            t1 = time.perf_counter()
+            step()
+            if use_dist:
+                torch.cuda.synchronize()
+            scene.sync()
+            lat.append((time.perf_counter() - t1) * 1e6)
+        lat.sort()
+        latency_us = {"median": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1)}
 
-    for i in range(orbit_frames):   # warm-up lap: lets the bins grow to what every angle needs
-        orbit_step(i)
-    device_idle()
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(orbit_frames):
-        orbit_step(i)
-    device_idle()
-    barrier()
-    orbit_elapsed = time.perf_counter() - t1
-    orbit_status = scene.sync()
+    # ---- read-back inclusive rate: every frame copied to page-locked host memory (the reference hands
+    # every frame to its window, app.rs:213-218); copies queue behind their frames, one sync at the end
+    readback = None
+    if extras and not use_dist:
+        pinned = [scene.pinned_frame() for _ in range(2)]
+        n_rb = 40
+        for k in range(4):
+            step()
+            scene.get_frame_buffer_async(pinned[k % 2])
+        scene.sync()
+        t1 = time.perf_counter()
+        for k in range(n_rb):
+            step()
+            scene.get_frame_buffer_async(pinned[k % 2])
+        scene.sync()
+        readback = (time.perf_counter() - t1) / n_rb
+
     step()  # back to the headline frame for the parity check below
     device_idle()
+    last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
 
-    # ---- per-kernel device time of the same step, HIP events on the scene's stream ------------
+    # ---- per-kernel device time of the same step, HIP events on the kernels' own dispatches ----------
     scene.profile_enable(True)
-    for _ in range(args.steps):
+    timing["on"] = use_dist
+    for _ in range(min(args.steps, 400) if use_dist else args.steps):
         step()
+    device_idle()
+    timing["on"] = False
+    for b in range(n_buf if use_dist else 0):
+        collect_times(b)
     prof = scene.profile_read()
+    intervals = np.sort(scene.profile_frame_intervals())
     scene.profile_enable(False)
+    last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
+
+    per_rank = None
+    if use_dist:
+        mine = {"rank": rank, "band_rows": list(band),
+                "render_us": round(float(np.median(timing["render_ms"])) * 1e3, 2) if timing["render_ms"] else None,
+                "gather_us": round(float(np.median(timing["gather_ms"])) * 1e3, 2) if timing["gather_ms"] else None,
+                "k_tile_us": round(prof["k_tile"]["total_ms"] / max(prof["k_tile"]["launches"], 1) * 1e3, 2)
+                if "k_tile" in prof else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     out = None
     if rank == 0:
@@ -228,7 +390,7 @@ def main():
         stats = cpu.stats()
         color = stats[1] if pipe in ("shadow", "occlusion") else stats[0]
         n_shaded = color["frag_accept"]
-        gpu_frame = fb.cpu().numpy().reshape(H, W, 3)
+        gpu_frame = fbs[last_buf].cpu().numpy().reshape(H, W, 3)
         ref_frame = cpu.get_frame_buffer()
         diff = np.abs(gpu_frame.astype(np.int16) - ref_frame.astype(np.int16))
         # specular calls powf: exact when the library reproduces the host libm's (tr_specular_exact), else 1 LSB
@@ -271,23 +433,44 @@ def main():
             avg_s = tile["total_ms"] / tile["launches"] / 1e3
             # one launch = one pass over the frame (or over this rank's band of it)
             ach = bytes_alg / world / avg_s / 1e9
-            traffic = None
+            traffic, traffic_note = None, "not profiled"
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
                 try:
-                    # HBM bytes of one k_tile launch from the rocprofv3 PMC passes of this workload
-                    # (FETCH_SIZE x2 + WRITE_SIZE, see profiles/pmc_traffic.json); null when this
-                    # workload has not been profiled
-                    entry = json.load(open(tf)).get(workload, {})
-                    # (profiled on one GPU: a band-sharded launch moves a different amount)
-                    traffic = entry.get("hbm_bytes_per_launch") if entry.get("kernel") == dom and world == 1 else None
-                except Exception:
-                    traffic = None
+                    # HBM bytes of one launch of the dominant kernel from the rocprofv3 PMC passes of this
+                    # workload (FETCH_SIZE x2 + WRITE_SIZE, separate passes).  Only reported when the
+                    # counters were collected on THIS source (fingerprint match) and on one GPU.
+                    db = json.load(open(tf))
+                    entry = db.get("workloads", {}).get(workload, {})
+                    if world != 1:
+                        traffic_note = "profiled on one GPU only"
+                    elif not entry:
+                        traffic_note = "workload not profiled"
+                    elif db.get("source_fingerprint") != source_fingerprint():
+                        traffic_note = "profiles/pmc_traffic.json was collected on other source (%s)" % db.get("source_fingerprint")
+                    elif entry.get("kernel") == dom:
+                        traffic = entry.get("hbm_bytes_per_launch")
+                        traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
+                except Exception as e:  # a malformed file must not take the bench down
+                    traffic, traffic_note = None, "unreadable pmc_traffic.json: %s" % e
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                        "traffic_source": traffic_note,
+                        # what actually crosses the HBM interface (the algorithmic model also counts the
+                        # z clear of empty tiles, which the fast-clear flags never write)
+                        "physical_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+                        "limiter": "vector/scalar instruction issue of the tiles with polygons, not HBM "
+                                   "(SQ counters under profiles/)",
                         "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_alg // world,
                         "algorithmic_bytes_per_frame": sum(bytes_by_kernel.values())}
         ms = elapsed / args.steps * 1e3
+        t_frame = None
+        if len(intervals):
+            t_frame = {"median": round(float(intervals[len(intervals) // 2]), 2),
+                       "p10": round(float(intervals[len(intervals) // 10]), 2),
+                       "p90": round(float(intervals[(len(intervals) * 9) // 10]), 2),
+                       "frames": int(len(intervals)),
+                       "what": "completion-to-completion of consecutive frames' tile kernels (HIP events, profiled loop)"}
         out = {
             "metric": "Mpixels/s shaded (z-test + Phong) at 4096x4096",
             "value": round(n_shaded * args.steps / elapsed / 1e6, 2),
@@ -301,13 +484,22 @@ def main():
             "data": data,
             "config": {"workload": workload, "n_shaded_per_frame": n_shaded,
                        "polygons": int(mesh["idx"].shape[0]),
-                       "sharding": "screen row bands + RCCL all-gather of the framebuffer" if use_dist else "none"},
+                       "sharding": ("screen row bands (tr_band_rows) + %s of the framebuffer%s" % (
+                           "RCCL all-gather" if exchange is None else "peer-to-peer band copies (tr_exchange)",
+                           "" if args.no_overlap else ", double-buffered: exchange of frame f under the render of f+1"))
+                       if use_dist else "none"},
+            "group_ranks": group_ranks if use_dist else 1,
             "frames_per_s": round(args.steps / elapsed, 1),
-            "frames_per_s_orbit": round(orbit_frames / orbit_elapsed, 1) if orbit_status == 0 else None,
+            "frames_per_s_orbit": round(orbit_frames / orbit_elapsed, 1) if orbit_elapsed and orbit_status == 0 else None,
             "framebuffer_mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
+            "t_frame_us": t_frame,
+            "latency_us": latency_us,
+            "readback_inclusive_mpixels_per_s": round(n_shaded / readback / 1e6, 1) if readback else None,
+            "readback_inclusive_frame_us": round(readback * 1e6, 1) if readback else None,
             "parity_vs_oracle": {"ok": parity_ok, "max_abs_rgb_diff": int(diff.max()), "tolerance": tol},
             "device_status": status,
             "kernel_us": {k: round(v["total_ms"] / max(v["launches"], 1) * 1e3, 2) for k, v in prof.items()},
+            "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
@@ -315,6 +507,8 @@ def main():
         sys.stdout.flush()
     if use_dist:
         dist.barrier()
+        if exchange is not None:
+            exchange.close()
         dist.destroy_process_group()
     scene.close()
     if out is not None and not out["parity_vs_oracle"]["ok"]:

@@ -127,6 +127,18 @@ int tr_scene_flush(tr_scene *s);                /* hand every render issued so f
                                                    may hold a few back to batch them); does not wait */
 void *tr_scene_frame_buffer_device(tr_scene *s); /* 3*W*H bytes, row 0 = top */
 int tr_scene_set_stream(tr_scene *s, void *hip_stream);
+/* Swap the render target: renders issued after the call write `frame_buffer_device` (3*W*H bytes of
+ * device memory, row 0 = top; NULL = the library's own buffer); renders already issued keep theirs.
+ * A pending `clear` carries over (the next render produces every pixel of the new buffer);
+ * without one the new buffer's content is taken as the frame so far.  For callers that double-buffer
+ * the frame, e.g. to exchange frame f between GPUs while frame f+1 renders. */
+int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device);
+
+/* Screen-band partition of a frame over the GPUs of a node (the reference's own clamp rectangle,
+ * scene.rs:236-239, cut into row bands): rank r of n renders output rows [row0, row1), row 0 = top
+ * -- the values for tr_options.band_row0/1.  Bands are disjoint, ordered by rank and cover the
+ * frame; they are equal (what an in-place all-gather needs) exactly when n divides height. */
+int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1);
 
 /* Diagnostic (TR_OPT_TILE_STAMPS): for each tile of the last colour pass {start, end} in 100 MHz
  * ticks, polygons in its bin, hardware id, {bin staged, coverage done} ticks, 2 spare.  `out`
@@ -142,6 +154,9 @@ typedef struct tr_kernel_time {
 int tr_scene_profile_enable(tr_scene *s, int on);
 /* Fills up to `cap` entries, returns the number of kernels or a negative status. */
 int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap);
+/* Frame times of the profiled renders: microseconds between the completions of consecutive frames'
+ * (colour-pass) tile kernels, in issue order.  Returns how many were written (<= cap). */
+int tr_scene_profile_frame_intervals(tr_scene *s, float *out_us, int cap);
 
 /* Device self-test of the arithmetic primitives the kernels substitute for the reference's:
  * Rust `as` casts (f32 -> u32 / i32 / u8) and x / d through a shared reciprocal.  Inputs and

@@ -76,6 +76,8 @@ def lib():
         L.tro_scene_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
         L.tro_scene_render.argtypes = [C.c_void_p]
         L.tro_scene_render.restype = C.c_int
+        L.tro_scene_set_output_band.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.tro_scene_set_output_band.restype = C.c_int
         for n in ("tro_scene_get_frame_buffer", "tro_scene_get_z_buffer", "tro_scene_get_shadow_buffer"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         L.tro_scene_z_f32.restype = C.POINTER(C.c_float)
@@ -166,6 +168,11 @@ class Scene:
 
     def set_camera(self, look_from, look_at, up):
         lib().tro_scene_set_camera(self._h, _f3(look_from), _f3(look_at), _f3(up))
+
+    def set_output_band(self, row0, row1):
+        """the colour pass's clamp rectangle cut to output rows [row0, row1) (row 0 = top)."""
+        if lib().tro_scene_set_output_band(self._h, int(row0), int(row1)) != 0:
+            raise ValueError("band rows must satisfy row0 < row1 <= height")
 
     def render(self):
         """Returns the TRO_E_* bitmask (0 = the reference would not have panicked)."""

@@ -235,6 +235,9 @@ struct tro_scene {
     tro_stats stats[2];
     int cur_pass;
     float occl_steps[48];
+    /* screen-band shard: the clamp rectangle of scene.rs:236-239 with its y range cut
+       to the rows [band_y0, band_y1] (internal rows, row 0 = bottom); whole frame by default */
+    int32_t band_y0, band_y1;
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -875,6 +878,8 @@ tro_scene *tro_scene_new(uint32_t width, uint32_t height, const tro_mesh *mesh,
     s->look_from[0] = 0.0f; s->look_from[1] = 0.0f; s->look_from[2] = 1.0f;
     s->look_at[0] = s->look_at[1] = s->look_at[2] = 0.0f;
     s->up[0] = 0.0f; s->up[1] = 1.0f; s->up[2] = 0.0f;
+    s->band_y0 = 0;
+    s->band_y1 = (int32_t)height - 1;
     return s;
 }
 
@@ -898,6 +903,17 @@ void tro_scene_clear(tro_scene *s)
         s->frame_buffer[3 * i + 2] = 0;
         s->winner[i] = 0xFFFFFFFFu;
     }
+}
+
+/* Not in the reference: restrict the colour pass to output rows [row0, row1) (row 0 = top, as
+ * get_frame_buffer returns them) by cutting the clamp rectangle of scene.rs:236-239 -- the shard
+ * hook SURVEY 8e names.  Pixels outside the band keep what they held. */
+int tro_scene_set_output_band(tro_scene *s, uint32_t row0, uint32_t row1)
+{
+    if (row0 >= row1 || row1 > s->height) return -1;
+    s->band_y0 = (int32_t)(s->height - row1);
+    s->band_y1 = (int32_t)(s->height - row0) - 1;
+    return 0;
 }
 
 void tro_scene_set_light_direction(tro_scene *s, const float v[3])
@@ -962,8 +978,11 @@ int tro_scene_render(tro_scene *s)
             int32_t ury = imax(imax(r[1], r[3]), r[5]);
             int32_t x_min = imax(0, llx);
             int32_t x_max = imin(urx, (int32_t)(s->width - 1u));
-            int32_t y_min = imax(0, lly);
-            int32_t y_max = imin(ury, (int32_t)(s->height - 1u));
+            /* depth passes fill the whole shadow buffer on every shard (lookups are in light space,
+               shader.rs:774-778); only the colour pass is cut to the band */
+            const int colour = (pi == s->n_passes - 1);
+            int32_t y_min = imax(colour ? s->band_y0 : 0, lly);
+            int32_t y_max = imin(ury, colour ? s->band_y1 : (int32_t)(s->height - 1u));
             for (int32_t i = x_min; i <= x_max; i++) {
                 for (int32_t j = y_min; j <= y_max; j++) {
                     st->bbox_px++;

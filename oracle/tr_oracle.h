@@ -93,6 +93,9 @@ void tro_scene_set_camera(tro_scene *s, const float from[3], const float at[3],
 /* Scene::render (scene.rs:151-268).  Returns 0 or the OR of TRO_E_* bits; on an error the
  * render stops at the panic site (buffers hold whatever was written so far). */
 int tro_scene_render(tro_scene *s);
+/* Not in the reference (SURVEY 8e's shard hook): cut the colour pass's clamp rectangle
+ * (scene.rs:236-239) to output rows [row0, row1), row 0 = top.  0 ok, -1 bad rows. */
+int tro_scene_set_output_band(tro_scene *s, uint32_t row0, uint32_t row1);
 
 /* scene.rs:92-125: rgb8 images, 3*W*H bytes, row 0 = top (flipped). */
 void tro_scene_get_frame_buffer(const tro_scene *s, uint8_t *rgb);

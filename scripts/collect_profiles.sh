@@ -2,8 +2,10 @@
 # Runs on the GPU box (through gpurun): collects the round's judged evidence into gpurun_out/prof/.
 #   bench line (with cpu_baseline), rocprofv3 kernel stats of the same bench command,
 #   HBM traffic counters (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, as
-#   MI355X_MICROARCH.md prescribes) and SQ instruction / cycle counters of a plain frame loop.
-# Copy what should be judged into profiles/ afterwards (scripts/summarise_profiles.py).
+#   MI355X_MICROARCH.md prescribes) for the headline workload and the five BASELINE configs,
+#   and SQ instruction / cycle counters of a plain frame loop of the headline workload.
+# Copy what should be judged into profiles/ afterwards (scripts/summarise_profiles.py <tag>), which
+# also stamps profiles/pmc_traffic.json with the fingerprint of the profiled sources.
 set -o pipefail
 out=gpurun_out/prof
 rm -rf "$out"; mkdir -p "$out"
@@ -14,14 +16,26 @@ python3 bench.py > "$out/bench_4096_phong.log" 2> "$out/bench_4096_phong.err" ||
 tail -n 1 "$out/bench_4096_phong.log"
 
 echo "== kernel trace"
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- python3 bench.py --no-cpu \
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- python3 bench.py --no-cpu --no-extras \
     > "$out/bench_under_rocprof.log" 2> "$out/trace.err" || exit 1
 tail -n 1 "$out/bench_under_rocprof.log"
 
-for c in FETCH_SIZE WRITE_SIZE; do
-  echo "== pmc $c"
-  rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$c" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 20 \
-      > "$out/pmc_$c.log" 2>&1 || exit 1
+# tag            size pipeline frames model        grid
+workloads=(
+ "headline       4096 phong    20     diablo       1"
+ "cfg0           800  default  20     african_head 1"
+ "cfg1           2048 phong    20     diablo       1"
+ "cfg2           4096 darboux  20     diablo       1"
+ "cfg3           4096 shadow   20     diablo       1"
+ "cfg4           8192 specular 6      diablo       8"
+)
+for w in "${workloads[@]}"; do
+  set -- $w
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "== pmc $c $1"
+    rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_${c}_$1" -o out --output-format csv -- python3 scripts/frame_loop.py $2 $3 $4 $5 $6 \
+        > "$out/pmc_${c}_$1.log" 2>&1 || exit 1
+  done
 done
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA"; do
@@ -30,4 +44,4 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYC
   rocprofv3 --pmc $set --kernel-trace -d "$out/sq_$n" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 12 \
       > "$out/sq_$n.log" 2>&1 || echo "counter set refused: $set"
 done
-find "$out" -name "*.csv" | head -40
+find "$out" -name "*.csv" | wc -l

@@ -1,4 +1,7 @@
-"""Minimal frame loop for profilers: N frames of one workload, nothing else on the GPU."""
+"""Minimal frame loop for profilers: N frames of one workload, nothing else on the GPU.
+
+    python scripts/frame_loop.py SIZE PIPELINE FRAMES [MODEL [GRID]]
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tiny_renderer_amd as T
@@ -6,8 +9,12 @@ from bench import find_assets, camera, light
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 pipe = sys.argv[2] if len(sys.argv) > 2 else "phong"
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-adir = find_assets("diablo")
+model = sys.argv[4] if len(sys.argv) > 4 else "diablo"
+grid = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+adir = find_assets(model)
 mesh, texs = T.load_assets(adir) if adir else T.synthetic_scene()
+if grid > 1:
+    mesh = T.instanced_grid(mesh, grid)
 s = T.Scene(size, size, mesh, texs, pipe)
 for _ in range(frames):
     s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()

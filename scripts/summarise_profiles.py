@@ -1,13 +1,29 @@
 """Turns gpurun_out/prof (scripts/collect_profiles.sh) into the files kept under profiles/.
 
-    python scripts/summarise_profiles.py [round-tag]     (default r01)
+    python scripts/summarise_profiles.py [round-tag]     (default r02)
+
+profiles/pmc_traffic.json is stamped with bench.source_fingerprint() of the tree it is run in: run it
+right after the GPU call, on the sources that were profiled; bench.py reports `roofline.traffic`
+only while that fingerprint matches.
 """
 import collections, csv, glob, json, os, shutil, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bench import source_fingerprint  # noqa: E402
+
 src = os.path.join(REPO, "gpurun_out", "prof")
 dst = os.path.join(REPO, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+WORKLOADS = {  # tag of collect_profiles.sh -> (bench workload string, dominant kernel)
+    "headline": ("diablo.obj, -s phong, 4096x4096", "k_tile"),
+    "cfg0": ("african_head.obj, -s default, 800x800", "k_tile"),
+    "cfg1": ("diablo.obj, -s phong, 2048x2048", "k_tile"),
+    "cfg2": ("diablo.obj, -s darboux, 4096x4096", "k_tile"),
+    "cfg3": ("diablo.obj, -s shadow, 4096x4096", "k_tile"),
+    "cfg4": ("diablo.obj x64 grid, -s specular, 8192x8192", "k_tile"),
+}
 
 
 def one(pattern):
@@ -18,7 +34,9 @@ def one(pattern):
 
 
 def kernel_of(name):
-    for k in ("k_tile", "k_setup", "k_order_count", "k_order_place", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
+    if "k_tile" in name:
+        return "k_tile_depth" if "<7," in name.replace(" ", "") or "FS_DEPTH" in name else "k_tile"
+    for k in ("k_setup", "k_order_count", "k_order_place", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
         if k in name:
             return k
     return name[:48]
@@ -37,27 +55,39 @@ shutil.copy(one("bench_4096_phong.log"), os.path.join(dst, tag + "_bench_4096_ph
 shutil.copy(one("bench_under_rocprof.log"), os.path.join(dst, tag + "_bench_4096_phong_under_rocprof.log"))
 shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats_4096_phong.csv"))
 
-traffic = counters("pmc_*")
+db = {"source_fingerprint": source_fingerprint(),
+      "correction": "gfx950: FETCH_SIZE x2 (128-B requests tallied at 64 B), WRITE_SIZE as is; separate --pmc passes "
+                    "(MI355X_MICROARCH.md, HBM); means over the launches of scripts/frame_loop.py",
+      "workloads": {}}
 rows = []
-for k, cs in sorted(traffic.items()):
-    for c, v in sorted(cs.items()):
-        rows.append((k, c, v))
+for wtag, (workload, dom) in WORKLOADS.items():
+    traffic = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k, cs in counters("pmc_%s_%s" % (c, wtag)).items():
+            traffic.setdefault(k, {}).update(cs)
+    if dom not in traffic:
+        print("no counters for", wtag)
+        continue
+    for k, cs in sorted(traffic.items()):
+        for c, v in sorted(cs.items()):
+            rows.append((wtag, k, c, v))
+    kt = traffic[dom]
+    fetch_kb, write_kb = kt.get("FETCH_SIZE", 0.0), kt.get("WRITE_SIZE", 0.0)
+    db["workloads"][workload] = {
+        "kernel": dom,
+        "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024.0)),
+        "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+        "other_kernels_kb": {k: cs for k, cs in traffic.items() if k != dom},
+        "source": "profiles/%s_pmc_fetch_write.csv" % tag}
 with open(os.path.join(dst, tag + "_pmc_fetch_write.csv"), "w") as f:
-    f.write("kernel,counter,mean_per_launch\n")
+    f.write("workload,kernel,counter,mean_per_launch_kb\n")
     for r in rows:
-        f.write("%s,%s,%.3f\n" % r)
-kt = traffic.get("k_tile", {})
-fetch_kb, write_kb = kt.get("FETCH_SIZE", 0.0), kt.get("WRITE_SIZE", 0.0)
-json.dump({"diablo.obj, -s phong, 4096x4096": {
-    "kernel": "k_tile",
-    "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024.0)),
-    "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-    "other_kernels_kb": {k: {c: v for c, v in cs.items()} for k, cs in traffic.items() if k != "k_tile"},
-    "correction": "gfx950: FETCH_SIZE x2 (128-B requests tallied at 64 B), WRITE_SIZE as is; separate --pmc passes (MI355X_MICROARCH.md, HBM)",
-    "source": "profiles/%s_pmc_fetch_write.csv" % tag}}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+        f.write("%s,%s,%s,%.3f\n" % r)
+json.dump(db, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 sq = counters("sq_*")
 json.dump({k: {c: round(v, 1) for c, v in cs.items()} for k, cs in sq.items() if k.startswith("k_")},
           open(os.path.join(dst, tag + "_pmc_sq_4096_phong.json"), "w"), indent=1, sort_keys=True)
-print(open(os.path.join(dst, tag + "_bench_4096_phong.log")).read().strip().splitlines()[-1])
-print(json.dumps(json.load(open(os.path.join(dst, "pmc_traffic.json"))), indent=1)[:600])
+print(open(os.path.join(dst, tag + "_bench_4096_phong.log")).read().strip().splitlines()[-1][:600])
+for w, e in db["workloads"].items():
+    print("%-50s %s %.1f MB/launch" % (w, e["kernel"], e["hbm_bytes_per_launch"] / 1e6))

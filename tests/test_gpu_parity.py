@@ -502,3 +502,102 @@ def test_random_api_sequences(small_synthetic, seed):
     assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer())
     assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
     gpu.close()
+
+
+@pytest.mark.parametrize("first", ["zview", "shadowview", "z", "winner", "frame"])
+def test_bin_overflow_first_getter(synthetic, first):
+    """Whatever getter is the first synchronising call after a render that overflowed the bins must
+    see the frame rendered again with grown bins, not a view derived from the truncated one."""
+    mesh, texs = synthetic
+    gpu, cpu = render_pair(256, 256, mesh, texs, "shadow", 0.3, 0.2, bin_capacity=64)
+    if first == "zview":
+        assert np.array_equal(gpu.get_z_buffer(), cpu.get_z_buffer())
+    elif first == "shadowview":
+        assert np.array_equal(gpu.get_shadow_buffer(), cpu.get_shadow_buffer())
+    elif first == "z":
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
+    elif first == "winner":
+        assert np.array_equal(gpu.read_winner_u32(), cpu.winner_u32())
+    assert_parity(gpu, cpu, "shadow")
+    gpu.close()
+
+
+def test_bin_overflow_with_reads_in_flight(synthetic):
+    """Frames whose bins overflowed and that were already copied out asynchronously cannot be
+    repaired behind the caller's back: sync must say TR_E_BIN_OVERFLOW (never TR_OK with a
+    truncated copy); after it the bins fit and the same sequence gives three correct frames."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = synthetic
+    W, Hh = 256, 256
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", bin_capacity=64)
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    outs = [gpu.pinned_frame() for _ in range(3)]
+
+    def burst():
+        for k, out in enumerate(outs):
+            gpu.clear()
+            gpu.set_light_direction(H.light(0.3 * k))
+            gpu.set_camera(*H.camera(0.9 * k))
+            gpu.render()
+            gpu.get_frame_buffer_async(out)
+
+    burst()
+    with pytest.raises(T.TinyRendererError) as e:
+        gpu.sync()
+    assert e.value.code == -9  # TR_E_BIN_OVERFLOW
+    burst()
+    assert gpu.sync() == 0
+    for k, out in enumerate(outs):
+        cpu.clear()
+        cpu.set_light_direction(H.light(0.3 * k))
+        cpu.set_camera(*H.camera(0.9 * k))
+        assert cpu.render() == 0
+        assert np.array_equal(out, cpu.get_frame_buffer()), "frame %d" % k
+    # frames that nobody observed are still repaired silently: only the last one can be seen
+    gpu2 = T.Scene(W, Hh, mesh, texs, "phong", bin_capacity=64)
+    for k in range(3):
+        gpu2.clear()
+        gpu2.set_light_direction(H.light(0.3 * k))
+        gpu2.set_camera(*H.camera(0.9 * k))
+        gpu2.render()
+    assert gpu2.sync() == 0
+    assert np.array_equal(gpu2.get_frame_buffer(), cpu.get_frame_buffer())
+    gpu.close()
+    gpu2.close()
+
+
+def test_caller_stream_consumes_frames_without_sync(small_synthetic):
+    """The multi-GPU bench's pattern on one GPU: the scene renders on a caller-provided (torch) side
+    stream into caller-provided, double-buffered frame tensors, and every frame is consumed ON THAT
+    STREAM (a device copy standing in for the all-gather) without any host synchronisation in
+    between; the camera moves, so a consumer that ran ahead of the render would keep a stale frame."""
+    import torch
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh, n = 1024, 640, 12
+    side = torch.cuda.Stream()
+    assert side.cuda_stream != 0
+    bufs = [torch.zeros(Hh * W * 3, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    kept = torch.zeros(n, Hh * W * 3, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", stream=side.cuda_stream, frame_buffer_device=bufs[0].data_ptr())
+    with torch.cuda.stream(side):
+        for f in range(n):
+            gpu.set_frame_buffer_device(bufs[f % 2].data_ptr())
+            gpu.clear()
+            gpu.set_light_direction(H.light(0.1 * f))
+            gpu.set_camera(*H.camera(0.45 * f))
+            gpu.render()
+            kept[f].copy_(bufs[f % 2], non_blocking=True)
+    assert gpu.sync() == 0
+    torch.cuda.synchronize()
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    for f in range(n):
+        cpu.clear()
+        cpu.set_light_direction(H.light(0.1 * f))
+        cpu.set_camera(*H.camera(0.45 * f))
+        assert cpu.render() == 0
+        assert np.array_equal(kept[f].cpu().numpy().reshape(Hh, W, 3), cpu.get_frame_buffer()), "frame %d" % f
+    gpu.close()

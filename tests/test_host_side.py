@@ -191,3 +191,26 @@ def test_synthetic_scene_and_instancing(built):
     g = T.instanced_grid(mesh, 8)
     assert g["idx"].shape == (5022 * 64, 9) and g["pos"].shape[0] == 64 * mesh["pos"].shape[0]
     assert g["idx"][:, 0::3].max() < g["pos"].shape[0] and np.abs(g["pos"][:, :2]).max() <= 1.0
+
+
+def test_band_rows_partition(built):
+    """tr_band_rows: disjoint, ordered, covering; equal bands when the rank count divides the height."""
+    import tiny_renderer_amd as T
+    for height, n in ((4096, 8), (4096, 1), (800, 3), (7, 7), (1080, 8), (8192, 4)):
+        rows = [T.band_rows(height, n, r) for r in range(n)]
+        assert rows[0][0] == 0 and rows[-1][1] == height
+        for a, b in zip(rows, rows[1:]):
+            assert a[1] == b[0]
+        assert all(r1 > r0 for r0, r1 in rows)
+        if height % n == 0:
+            assert len({r1 - r0 for r0, r1 in rows}) == 1
+    with pytest.raises(T.TinyRendererError):
+        T.band_rows(4, 8, 0)
+    with pytest.raises(T.TinyRendererError):
+        T.band_rows(64, 4, 4)
+
+
+def test_specular_exact_is_checked_on_this_host(built):
+    """tr_specular_exact() compares the shipped powf with the running C library's at first use."""
+    import tiny_renderer_amd as T
+    assert T.load_library().tr_specular_exact() == 1  # this image and the GPU box: glibc 2.35, same tables

@@ -1,6 +1,14 @@
-"""N>1 path on the CPU: two gloo ranks each produce their band of the frame (from the oracle:
-no GPU here) and all-gather it exactly as bench.py does with RCCL -- checks the band
-arithmetic, the in-place all_gather_into_tensor layout and rank-0 assembly."""
+"""N>1 path on the CPU (gloo, world size 2 and 3): every rank asks the PRODUCT's partition function
+(tr_band_rows, through the C ABI) for its band, renders ONLY that band -- with the oracle, whose
+clamp rectangle (scene.rs:236-239) is cut to the band exactly as k_setup cuts it on the GPU -- into
+its slice of a full-frame tensor, and the bands are exchanged with the in-place
+all_gather_into_tensor bench.py issues over RCCL.  The gathered frame must equal the single-rank
+frame byte for byte: overlapping, gapped, unequal or mis-ordered bands all fail here, and so does
+a double-buffering scheme that hands a slot back too early (two frames in flight, moving camera).
+
+The GPU side of the same contract (bands rendered by the HIP path, a caller's stream, two frame
+tensors) is tests/test_gpu_parity.py::test_band_shards_reassemble and
+::test_caller_stream_consumes_frames_without_sync."""
 import os
 import socket
 import sys
@@ -11,7 +19,7 @@ import pytest
 from tests import helpers as H
 
 
-def _worker(rank, world, port, W, Hh, q):
+def _worker(rank, world, port, W, Hh, pipe, q):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, H.REPO)
@@ -20,36 +28,69 @@ def _worker(rank, world, port, W, Hh, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    mesh, texs = T.synthetic_scene(n_lat=10, n_lon=20, tex_size=128)
-    s = O.Scene(W, Hh, mesh, texs, "phong")
-    s.clear()
-    s.set_light_direction(H.light(0.2))
-    s.set_camera(*H.camera(0.4))
-    s.render()
-    full_ref = s.get_frame_buffer()
-    rows = [(r * Hh) // world for r in range(world + 1)]
-    fb = torch.zeros(Hh * W * 3, dtype=torch.uint8)
-    n = (rows[rank + 1] - rows[rank]) * W * 3
-    chunk = fb[rank * n:(rank + 1) * n]
-    chunk.copy_(torch.from_numpy(full_ref[rows[rank]:rows[rank + 1]].reshape(-1)))  # this rank's band only
-    dist.all_gather_into_tensor(fb, chunk)
-    ok = np.array_equal(fb.numpy().reshape(Hh, W, 3), full_ref)
-    dist.barrier()
-    dist.destroy_process_group()
+    ok = True
+    try:
+        assert dist.get_world_size() == world
+        mesh, texs = T.synthetic_scene(n_lat=10, n_lon=20, tex_size=128)
+        row0, row1 = T.band_rows(Hh, world, rank)            # the product's partition, via the C ABI
+        n = (row1 - row0) * W * 3
+        assert n * world == Hh * W * 3, "in-place all-gather needs equal bands"
+        full = O.Scene(W, Hh, mesh, texs, pipe)              # what one GPU would render
+        mine = O.Scene(W, Hh, mesh, texs, pipe)              # this rank: its band only
+        mine.set_output_band(row0, row1)
+        fbs = [torch.zeros(Hh * W * 3, dtype=torch.uint8) for _ in range(2)]   # double-buffered, as in bench.py
+        works = [None, None]
+        for f in range(4):
+            b = f % 2
+            if works[b] is not None:
+                works[b].wait()                              # slot free again (bench: render waits for `gathered[b]`)
+                ok = ok and np.array_equal(fbs[b].numpy().reshape(Hh, W, 3), expect[b])
+            for s in (full, mine):
+                s.clear()
+                s.set_light_direction(H.light(0.2 + 0.1 * f))
+                s.set_camera(*H.camera(0.4 * f))
+                assert s.render() == 0
+            band = mine.get_frame_buffer()[row0:row1]
+            # rows outside the band stay cleared: the shard really rendered its band only
+            outside = np.delete(mine.get_frame_buffer(), np.s_[row0:row1], axis=0)
+            ok = ok and not outside.any()
+            chunk = fbs[b][rank * n:(rank + 1) * n]
+            chunk.copy_(torch.from_numpy(np.ascontiguousarray(band).reshape(-1)))
+            if f == 0:
+                expect = [None, None]
+            expect[b] = full.get_frame_buffer()
+            works[b] = dist.all_gather_into_tensor(fbs[b], chunk, async_op=True)   # exchange of f under the render of f+1
+        for b in range(2):
+            works[b].wait()
+            ok = ok and np.array_equal(fbs[b].numpy().reshape(Hh, W, 3), expect[b])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
     q.put((rank, bool(ok)))
 
 
-def test_two_rank_band_allgather():
+@pytest.mark.parametrize("world,pipe", [(2, "phong"), (2, "shadow"), (3, "phong")])
+def test_band_allgather_ranks(built, world, pipe):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 96, 64, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 66 if world == 3 else 64, pipe, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_bench_refuses_mismatched_world(built):
+    """`bench.py --gpus N` inside a launcher whose WORLD_SIZE is not N must not run (it used to print a
+    1-GPU number); without a launcher and with N > 1 it starts the ranks itself (checked on the GPU box)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)

@@ -7,10 +7,10 @@ tests, the bench and the headless CLI.  There is no CPU rendering path: creating
 without the built library or without a GPU raises.
 """
 from ._lib import build_library, library_path, load_library, TinyRendererError  # noqa: F401
-from .scene import Scene, PIPELINES, prepare_uniforms  # noqa: F401
+from .scene import Scene, PIPELINES, prepare_uniforms, band_rows  # noqa: F401
 from .assets import load_assets, load_obj, load_tga, save_tga  # noqa: F401
 from .synthetic import synthetic_scene, instanced_grid  # noqa: F401
 
-__all__ = ["Scene", "PIPELINES", "prepare_uniforms", "load_assets", "load_obj", "load_tga", "save_tga",
+__all__ = ["Scene", "PIPELINES", "prepare_uniforms", "band_rows", "load_assets", "load_obj", "load_tga", "save_tga",
            "synthetic_scene", "instanced_grid", "build_library", "library_path", "load_library",
            "TinyRendererError"]

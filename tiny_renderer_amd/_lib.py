@@ -81,9 +81,12 @@ SYMBOLS = {
     "tr_scene_flush": (C.c_int, [C.c_void_p]),
     "tr_scene_frame_buffer_device": (C.c_void_p, [C.c_void_p]),
     "tr_scene_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_scene_set_frame_buffer_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_band_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "tr_scene_debug_tile_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "tr_scene_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tr_scene_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int]),
+    "tr_scene_profile_frame_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tr_selftest_device_math": (C.c_int, [C.c_int, _FP, _FP, C.c_uint32] + [C.c_void_p] * 5),
     "tr_pipeline_count": (C.c_int, []),
     "tr_pipeline_name": (C.c_char_p, [C.c_int]),

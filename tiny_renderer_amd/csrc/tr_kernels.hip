@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
             } else {
                 atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
                 atomicMax(a.bin_need, slot[k] + 1u);
+                atomicMin(a.overflow_seq, a.pass_seq);
             }
         }
     }

@@ -8,6 +8,7 @@
 // There is no CPU rendering path in this library.  If HIP or a gfx950 device is not usable,
 // tr_scene_create fails with TR_E_HIP.
 #include <hip/hip_runtime_api.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -19,6 +20,7 @@
 #include "tr_error.h"
 #include "tr_kernels.h"
 #include "tr_math.h"
+#include "tr_powf.h"
 #include "tr_prepare.h"
 #include "tr_types.h"
 
@@ -148,13 +150,21 @@ struct tr_scene {
         TileArgs args;
     };
     std::vector<PendingTile> pending;  // passes whose setup is queued and whose tile kernel is not yet
+    uint64_t tiles_submitted = 0;      // tile kernels handed to the main stream so far
+    uint64_t last_submitted_seq = 0;   // pass number of the newest of them (its ev_tile tells whether the stream is idle)
     uint32_t tile_waves = 0;     // tr_options.tile_waves: 4, 8 or 0 = by tile count
     uint32_t bin_cap = 0;        // records per tile; grown on overflow
     uint32_t rec_pieces = 0;
     uint32_t *d_bin_need = nullptr;
+    // First pass (global pass number) whose bins overflowed since the last sync, written by k_setup
+    // with an atomic minimum; ~0 = none.  Frames older than the last one cannot be rendered again,
+    // so sync compares it with `observed_seq`: passes below that number have been handed to a
+    // consumer the library cannot call back (an asynchronous read-back, or a caller's stream).
+    unsigned long long *d_overflow_seq = nullptr;
+    uint64_t observed_seq = 0;
     float *d_z = nullptr, *d_shadow = nullptr;
-    uint8_t *d_fb = nullptr;
-    bool own_fb = false;
+    uint8_t *d_fb = nullptr;      // where the next render writes
+    uint8_t *d_fb_own = nullptr;  // the library's own buffer (allocated when first needed)
     uint8_t *d_view = nullptr;  // scratch for get_z_buffer / get_shadow_buffer
     uint32_t *d_winner = nullptr;
     // Fast depth clear: one word per colour-pass tile, non-zero = "every z of the tile is f32::MIN,
@@ -186,6 +196,7 @@ struct tr_scene {
     std::vector<hipEvent_t> event_pool;
     double prof_ms[K_COUNT] = {};
     uint64_t prof_n[K_COUNT] = {};
+    std::vector<float> frame_intervals_us;  // completion-to-completion time of consecutive colour-pass tile kernels
 };
 
 namespace {
@@ -239,11 +250,20 @@ struct Timed {
 
 int drain_events(tr_scene *s)
 {
+    hipEvent_t prev_frame_end = nullptr;
     for (const EventPair &ep : s->events) {
         float ms = 0.0f;
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             s->prof_ms[ep.kernel] += ms;
             s->prof_n[ep.kernel] += 1;
+        }
+        if (ep.kernel == K_TILE) {
+            // a frame ends with its colour pass: the spacing of those completions is the frame time
+            // of the running pipeline (frames overlap; a kernel's own duration says less)
+            if (prev_frame_end && hipEventElapsedTime(&ms, prev_frame_end, ep.b) == hipSuccess &&
+                s->frame_intervals_us.size() < (1u << 20))
+                s->frame_intervals_us.push_back(ms * 1000.0f);
+            prev_frame_end = ep.b;
         }
         s->event_pool.push_back(ep.a);
         s->event_pool.push_back(ep.b);
@@ -278,6 +298,8 @@ int submit_pending(tr_scene *s)
                 status = tr::fail(TR_E_HIP, "hipEventRecord");
         }
     }
+    s->tiles_submitted += s->pending.size();
+    s->last_submitted_seq = s->pending.back().p_seq;
     s->pending.clear();
     return status;
 }
@@ -333,11 +355,16 @@ int materialize_depth(tr_scene *s)
 
 int render_frame(tr_scene *s);
 
-// A tile received more polygons than its bin holds.  Grow the bins to what the frame asked for
-// and render it again from the state it started in.  That is exact when the frame started from
-// cleared targets (the per-frame protocol of app.rs:170-210); an accumulating render cannot be
-// replayed, so it reports TR_E_BIN_OVERFLOW after growing and the caller clears and renders again.
-int recover_from_overflow(tr_scene *s)
+// A tile received more polygons than its bin holds (k_tile then works on the first bin_cap records
+// only: a truncated frame).  Grow the bins to what the passes asked for, then:
+//   * if an overflowed pass has already been handed to a consumer the library cannot call back --
+//     an asynchronous read-back queued behind it, or a caller-provided stream, whose next
+//     operation may have used the frame -- report TR_E_BIN_OVERFLOW: the caller renders (and
+//     copies) again, now with bins that fit;
+//   * otherwise only the last frame can still be observed: render it again from the state it
+//     started in.  Exact when that frame started from cleared targets (the per-frame protocol of
+//     app.rs:170-210); an accumulating render cannot be replayed and reports TR_E_BIN_OVERFLOW.
+int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
 {
     uint32_t need = 0;
     HIP_TRY(hipMemcpy(&need, s->d_bin_need, sizeof need, hipMemcpyDeviceToHost));
@@ -356,6 +383,10 @@ int recover_from_overflow(tr_scene *s)
         st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces);
     }
     if (st != TR_OK) return st;
+    if (first_bad_seq < s->observed_seq)
+        return tr::fail(TR_E_BIN_OVERFLOW,
+                        "triangle bins overflowed in a frame that was already handed on (asynchronous read-back or "
+                        "caller's stream): that frame is truncated; the bins have been grown: render it again");
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
     if (!replayable)
@@ -376,6 +407,20 @@ int recover_from_overflow(tr_scene *s)
     return st;
 }
 
+// Reads and resets the device error word and the overflow bookkeeping (stream idle).
+int take_device_errors(tr_scene *s, uint32_t &err, unsigned long long &first_bad_seq)
+{
+    err = 0;
+    first_bad_seq = ~0ull;
+    HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
+    if (err & DE_BIN_OVERFLOW) {
+        HIP_TRY(hipMemcpy(&first_bad_seq, s->d_overflow_seq, sizeof first_bad_seq, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(s->d_overflow_seq, 0xFF, sizeof first_bad_seq));
+    }
+    return TR_OK;
+}
+
 // Waits for the stream and folds the device error word into a status.
 int sync_and_status(tr_scene *s)
 {
@@ -386,19 +431,25 @@ int sync_and_status(tr_scene *s)
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
-    if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
-    if (s->host_status != TR_OK) return s->host_status;
+    unsigned long long first_bad = ~0ull;
+    {
+        int st = take_device_errors(s, err, first_bad);
+        if (st != TR_OK) return st;
+    }
+    const int host_status = s->host_status;
     if (err & DE_BIN_OVERFLOW) {
-        int st = recover_from_overflow(s);
+        int st = recover_from_overflow(s, first_bad);
+        s->observed_seq = 0;  // everything issued so far has completed; later hand-offs count afresh
         if (st != TR_OK) return st;
         st = submit_pending(s);
         if (st != TR_OK) return st;
         HIP_TRY(hipStreamSynchronize(s->stream));
-        HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
-        if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));
+        st = take_device_errors(s, err, first_bad);
+        if (st != TR_OK) return st;
         if (err & DE_BIN_OVERFLOW) return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins overflowed twice");
     }
+    s->observed_seq = 0;
+    if (host_status != TR_OK) return host_status;
     if (err & (DE_W_ZERO | DE_TEX_OOB | DE_SHADOW_OOB | DE_SINGULAR)) {
         char buf[160];
         snprintf(buf, sizeof buf,
@@ -468,6 +519,8 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.rec_pieces = s->rec_pieces;
     sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
+    sa.overflow_seq = s->d_overflow_seq;
+    sa.pass_seq = p_seq;
     // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p
     if (p_seq >= (uint64_t)LOOKAHEAD)
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
@@ -524,8 +577,17 @@ int run_pass(tr_scene *s, const PassDesc &p)
     bs.seq++;
     s->pass_seq++;
     // a caller's stream must hold the frame when render() returns (its next operation may consume
-    // it); on the library's own stream up to BATCH passes wait for company
-    if ((int)s->pending.size() >= BATCH || !s->own_stream) return submit_pending(s);
+    // it: from here on the pass counts as handed on, see recover_from_overflow)
+    if (!s->own_stream) {
+        s->observed_seq = s->pass_seq;
+        return submit_pending(s);
+    }
+    // on the library's own stream up to BATCH passes wait for company -- but only while the main
+    // stream still has tile kernels to run: holding work back from an idle queue (the first frames
+    // after a sync) would leave the GPU waiting for the host to issue three more frames
+    if ((int)s->pending.size() >= BATCH) return submit_pending(s);
+    if (s->tiles_submitted == 0 || hipEventQuery(s->ev_tile[(s->last_submitted_seq) % RING]) == hipSuccess)
+        return submit_pending(s);
     return TR_OK;
 }
 
@@ -581,9 +643,10 @@ void destroy(tr_scene *s)
         dev_free(s->d_bins[k]);
     }
     dev_free(s->d_bin_need);
+    dev_free(s->d_overflow_seq);
     dev_free(s->d_z);
     dev_free(s->d_shadow);
-    if (s->own_fb) dev_free(s->d_fb);
+    dev_free(s->d_fb_own);
     dev_free(s->d_view);
     dev_free(s->d_winner);
     dev_free(s->d_zclean);
@@ -711,6 +774,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         HIP_TRY(hipEventCreateWithFlags(&s->ev_tile[k], hipEventDisableTiming));
     }
     HIP_TRY(hipMemset(s->d_bin_need, 0, 4));
+    if ((st = dev_alloc(&s->d_overflow_seq, 1))) return st;
+    HIP_TRY(hipMemset(s->d_overflow_seq, 0xFF, sizeof(unsigned long long)));
 
     // render targets; Buffer::new / Scene::new zero-fill them (shader.rs:46-47, scene.rs:71)
     if ((st = dev_alloc(&s->d_z, npx))) return st;
@@ -722,9 +787,9 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if (o.frame_buffer_device) {
         s->d_fb = (uint8_t *)o.frame_buffer_device;
     } else {
-        if ((st = dev_alloc(&s->d_fb, npx * 3))) return st;
-        s->own_fb = true;
-        HIP_TRY(hipMemset(s->d_fb, 0, npx * 3));
+        if ((st = dev_alloc(&s->d_fb_own, npx * 3))) return st;
+        HIP_TRY(hipMemset(s->d_fb_own, 0, npx * 3));
+        s->d_fb = s->d_fb_own;
     }
     if (o.flags & TR_OPT_WINNER_TAP) {
         if ((st = dev_alloc(&s->d_winner, npx))) return st;
@@ -740,27 +805,53 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     return TR_OK;
 }
 
-int read_back(tr_scene *s, void *dst, const void *src, size_t bytes)
+// Getters run in this order: (1) wait for the frame and take its status -- a bin overflow found
+// here grows the bins and renders the frame again; (2) only then enqueue what derives from the
+// frame (a pending clear, the fast-clear flags' f32::MIN, the u8 depth view); (3) wait, copy.
+// Deriving first would copy out a view of the truncated frame.  The frame's status is returned
+// after the copy (TR_E_OOB_LOOKUP / TR_E_BIN_OVERFLOW frames are still delivered); TR_E_HIP ends
+// the call.
+bool fatal(int st) { return st == TR_E_HIP || st == TR_E_NOMEM || st == TR_E_INVALID; }
+
+int finish_read_back(tr_scene *s, int frame_status, void *dst, const void *src, size_t bytes)
 {
-    int st = sync_and_status(s);
+    HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-    return st;
+    return frame_status;
 }
 
-int depth_view(tr_scene *s, const float *src, uint8_t *rgb)
+int depth_view(tr_scene *s, int frame_status, const float *src, uint8_t *rgb)
 {
     const size_t npx = (size_t)s->width * s->height;
     if (!s->d_view) {
         int st = dev_alloc(&s->d_view, npx * 3);
         if (st) return st;
     }
-    {
-        int sp = submit_pending(s);
-        if (sp != TR_OK) return sp;
-    }
     int rc = launch_depth_view(src, s->d_view, s->width, s->height, s->stream);
     if (rc) return launch_status(rc, "k_depth_view");
-    return read_back(s, rgb, s->d_view, npx * 3);
+    return finish_read_back(s, frame_status, rgb, s->d_view, npx * 3);
+}
+
+// Runs at the first use: does tr_powf (tr_powf.h: glibc's algorithm with the tables the BUILD
+// host's libm held) return what the powf of the C library this process RUNS with returns?  The
+// library may be built on one machine and loaded on another; the specular closure's
+// "bit for bit the host's powf" only holds when the two agree.
+int powf_matches_this_host()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    if (!tr::specular_is_exact()) return cached = 0;
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    int ok = 1;
+    for (int i = 0; i < 20000 && ok; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        // the closure's domain: base max(r.z, 0) in [0, 1], exponent 0..255 (util.rs:82)
+        const float base = (i % 97 == 0) ? 0.0f : (i % 89 == 0) ? 1.0f : (float)((x >> 11) & 0xFFFFFFu) / 16777216.0f;
+        const float e = (float)((x >> 40) & 0xFFu);
+        const float a = tr::tr_powf(base, e), b = powf(base, e);
+        if (memcmp(&a, &b, 4) != 0) ok = 0;
+    }
+    return cached = ok;
 }
 
 }  // namespace
@@ -772,7 +863,7 @@ extern "C" {
 
 int tr_abi_version(void) { return TR_ABI_VERSION; }
 
-int tr_specular_exact(void) { return tr::specular_is_exact(); }
+int tr_specular_exact(void) { return powf_matches_this_host(); }
 
 const char *tr_last_error(void) { return tr::g_last_error.c_str(); }
 
@@ -886,6 +977,33 @@ int tr_scene_sync(tr_scene *s)
 
 void *tr_scene_frame_buffer_device(tr_scene *s) { return s ? s->d_fb : nullptr; }
 
+int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    if (frame_buffer_device) {
+        s->d_fb = (uint8_t *)frame_buffer_device;
+        return TR_OK;
+    }
+    if (!s->d_fb_own) {
+        const size_t n = (size_t)s->width * s->height * 3;
+        int st = dev_alloc(&s->d_fb_own, n);
+        if (st) return st;
+        HIP_TRY(hipMemsetAsync(s->d_fb_own, 0, n, s->stream));
+    }
+    s->d_fb = s->d_fb_own;
+    return TR_OK;
+}
+
+int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1)
+{
+    if (!row0 || !row1 || n_ranks == 0 || rank >= n_ranks || height < n_ranks)
+        return tr::fail(TR_E_INVALID, "tr_band_rows: need rank < n_ranks <= height");
+    *row0 = (uint32_t)(((uint64_t)rank * height) / n_ranks);
+    *row1 = (uint32_t)(((uint64_t)(rank + 1u) * height) / n_ranks);
+    return TR_OK;
+}
+
 int tr_scene_set_stream(tr_scene *s, void *hip_stream)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
@@ -909,10 +1027,11 @@ int tr_scene_set_stream(tr_scene *s, void *hip_stream)
 int tr_scene_get_frame_buffer(tr_scene *s, uint8_t *rgb)
 {
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
+    int fst = sync_and_status(s);
+    if (fatal(fst)) return fst;
     int st = flush_clear_color(s);
     if (st != TR_OK) return st;
-    return read_back(s, rgb, s->d_fb, (size_t)s->width * s->height * 3);
+    return finish_read_back(s, fst, rgb, s->d_fb, (size_t)s->width * s->height * 3);
 }
 
 int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
@@ -925,6 +1044,9 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
     if (st != TR_OK) return st;
     // same stream as the tile kernels: after the frame, before the next one overwrites it
     HIP_TRY(hipMemcpyAsync(rgb, s->d_fb, (size_t)s->width * s->height * 3, hipMemcpyDeviceToHost, s->stream));
+    // every pass issued so far is now in a consumer's hands: a bin overflow among them can no longer
+    // be repaired by rendering again, and tr_scene_sync will say so (TR_E_BIN_OVERFLOW)
+    s->observed_seq = s->pass_seq;
     return TR_OK;
 }
 
@@ -943,49 +1065,54 @@ void tr_host_free(void *p)
 int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb)
 {
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
+    int fst = sync_and_status(s);
+    if (fatal(fst)) return fst;
     int st = flush_clear_color(s);
     if (st == TR_OK) st = materialize_depth(s);
     if (st != TR_OK) return st;
-    return depth_view(s, s->d_z, rgb);
+    return depth_view(s, fst, s->d_z, rgb);
 }
 
 int tr_scene_get_shadow_buffer(tr_scene *s, uint8_t *rgb)
 {
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
+    int fst = sync_and_status(s);
+    if (fatal(fst)) return fst;
     int st = flush_clear_shadow(s);
     if (st != TR_OK) return st;
-    return depth_view(s, s->d_shadow, rgb);
+    return depth_view(s, fst, s->d_shadow, rgb);
 }
 
 int tr_scene_read_z_f32(tr_scene *s, float *out)
 {
     if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
+    int fst = sync_and_status(s);
+    if (fatal(fst)) return fst;
     int st = flush_clear_color(s);
     if (st == TR_OK) st = materialize_depth(s);
     if (st != TR_OK) return st;
-    return read_back(s, out, s->d_z, (size_t)s->width * s->height * 4);
+    return finish_read_back(s, fst, out, s->d_z, (size_t)s->width * s->height * 4);
 }
 
 int tr_scene_read_shadow_f32(tr_scene *s, float *out)
 {
     if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
+    int fst = sync_and_status(s);
+    if (fatal(fst)) return fst;
     int st = flush_clear_shadow(s);
     if (st != TR_OK) return st;
-    return read_back(s, out, s->d_shadow, (size_t)s->width * s->height * 4);
+    return finish_read_back(s, fst, out, s->d_shadow, (size_t)s->width * s->height * 4);
 }
 
 int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out)
 {
     if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
     if (!s->d_winner) return tr::fail(TR_E_INVALID, "scene was created without TR_OPT_WINNER_TAP");
-    HIP_TRY(hipSetDevice(s->device));
+    int fst = sync_and_status(s);
+    if (fatal(fst)) return fst;
     int st = flush_clear_color(s);
     if (st != TR_OK) return st;
-    return read_back(s, out, s->d_winner, (size_t)s->width * s->height * 4);
+    return finish_read_back(s, fst, out, s->d_winner, (size_t)s->width * s->height * 4);
 }
 
 int tr_scene_debug_tile_stamps(tr_scene *s, uint64_t *out, uint32_t cap_tiles)
@@ -1017,6 +1144,7 @@ int tr_scene_profile_enable(tr_scene *s, int on)
     if (on) {
         memset(s->prof_ms, 0, sizeof s->prof_ms);
         memset(s->prof_n, 0, sizeof s->prof_n);
+        s->frame_intervals_us.clear();
     }
     return TR_OK;
 }
@@ -1040,6 +1168,21 @@ int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap)
         out[n].total_ms = s->prof_ms[k];
         n++;
     }
+    return n;
+}
+
+int tr_scene_profile_frame_intervals(tr_scene *s, float *out_us, int cap)
+{
+    if (!s || !out_us || cap <= 0) return tr::fail(TR_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    drain_events(s);
+    const int n = (int)s->frame_intervals_us.size() < cap ? (int)s->frame_intervals_us.size() : cap;
+    memcpy(out_us, s->frame_intervals_us.data(), (size_t)n * sizeof(float));
     return n;
 }
 

@@ -170,6 +170,9 @@ struct SetupArgs {
     uint32_t rec_pieces;
     uint32_t *bin_need;
     uint32_t *err;
+    // overflow bookkeeping: the smallest `pass_seq` of a pass that overflowed a bin (atomic minimum)
+    unsigned long long *overflow_seq;
+    unsigned long long pass_seq;
 };
 
 struct TileArgs {

@@ -154,6 +154,10 @@ class Scene:
     def frame_buffer_device(self):
         return load_library().tr_scene_frame_buffer_device(self._h)
 
+    def set_frame_buffer_device(self, ptr):
+        """Renders issued from now on write the device buffer at `ptr` (None: the library's own)."""
+        check(load_library().tr_scene_set_frame_buffer_device(self._h, ptr))
+
     def set_stream(self, stream):
         check(load_library().tr_scene_set_stream(self._h, stream))
 
@@ -172,6 +176,23 @@ class Scene:
         n = check(load_library().tr_scene_profile_read(self._h, buf, 16))
         return {buf[i].name.decode(): {"launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms)}
                 for i in range(n)}
+
+
+def _frame_intervals(self, cap=1 << 16):
+    """Microseconds between the completions of consecutive profiled frames (float32 array)."""
+    out = np.zeros(cap, np.float32)
+    n = check(load_library().tr_scene_profile_frame_intervals(self._h, out.ctypes.data, cap))
+    return out[:n]
+
+
+Scene.profile_frame_intervals = _frame_intervals
+
+
+def band_rows(height, n_ranks, rank):
+    """Output rows [row0, row1) rank `rank` of `n_ranks` renders (tr_band_rows, include/tiny_renderer.h)."""
+    r0, r1 = C.c_uint32(), C.c_uint32()
+    check(load_library().tr_band_rows(height, n_ranks, rank, C.byref(r0), C.byref(r1)))
+    return int(r0.value), int(r1.value)
 
 
 def prepare_uniforms(kind, width, height, light, look_from, look_at, up, uniforms=None):
