@@ -164,6 +164,13 @@ int tr_scene_profile_frame_intervals(tr_scene *s, float *out_us, int cap);
 int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t n, uint32_t *out_u32,
                             int32_t *out_i32, uint32_t *out_u8, float *out_div, float *out_div_ref);
 
+/* Exhaustive device check of the kernels' own correctly rounded reciprocal (which = 0) and square
+ * root (which = 1) for pixel pairs (csrc/tr_pk.h rcp2 / sqrt2: hardware estimate + fused residual
+ * corrections) against the compiler's IEEE `1.0f / x` and `sqrtf`: every f32 with binary exponent in
+ * [exp_lo, exp_hi].  n_bad counts differing results, bad_bits receives up to 16 of the arguments. */
+int tr_selftest_device_unary(int device, int which, int exp_lo, int exp_hi, uint64_t *n_tested, uint64_t *n_bad,
+                             uint32_t bad_bits[16]);
+
 /* 1 when this build's specular pipeline (shader.rs:472-543, the only one that calls powf) returns
  * the host C library's powf bit for bit -- the library was built against a glibc whose powf
  * tables it could read (csrc/gen_powf_tables.py); 0: the device library's powf, within 1 ulp. */

@@ -6,8 +6,12 @@ import tiny_renderer_amd as T
 from bench import find_assets, camera, light
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 pipe = sys.argv[2] if len(sys.argv) > 2 else "phong"
-adir = find_assets("diablo")
+model = sys.argv[3] if len(sys.argv) > 3 else "diablo"
+grid = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+adir = find_assets(model)
 mesh, texs = T.load_assets(adir) if adir else T.synthetic_scene()
+if grid > 1:
+    mesh = T.instanced_grid(mesh, grid)
 s = T.Scene(size, size, mesh, texs, pipe, tile_stamps=True)
 for _ in range(5):
     s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()

@@ -58,19 +58,53 @@ bool run_vs(int vs, const DevMesh &m, const DevUniforms &u, uint32_t t, RasterRe
     }
 }
 
-uint32_t run_fs(int fs, const DevUniforms &u, const DevTextures &tx, const float *vary, vec3 bar, uint32_t x,
-                uint32_t y, float z, const float *shadow, uint32_t W, uint32_t H, uint32_t &err)
+uint32_t run_fs_color(int fs, const DevUniforms &u, const DevTextures &tx, const float *vary, vec3 bar, float uu, float vv,
+                      uint32_t x, uint32_t y, float z, const float *shadow, uint32_t W, uint32_t H, uint32_t &err)
 {
     switch (fs) {
-    case FS_DEFAULT: return fragment_stage<FS_DEFAULT>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
-    case FS_PHONG: return fragment_stage<FS_PHONG>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
-    case FS_NORMAL_MAP: return fragment_stage<FS_NORMAL_MAP>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
-    case FS_SPECULAR: return fragment_stage<FS_SPECULAR>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
-    case FS_DARBOUX: return fragment_stage<FS_DARBOUX>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
-    case FS_SHADOW2: return fragment_stage<FS_SHADOW2>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
-    case FS_OCCLUSION2: return fragment_stage<FS_OCCLUSION2>(u, tx, vary, bar, x, y, z, shadow, W, H, err);
+    case FS_DEFAULT: return fragment_color<FS_DEFAULT>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    case FS_PHONG: return fragment_color<FS_PHONG>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    case FS_NORMAL_MAP: return fragment_color<FS_NORMAL_MAP>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    case FS_SPECULAR: return fragment_color<FS_SPECULAR>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    case FS_DARBOUX: return fragment_color<FS_DARBOUX>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    case FS_SHADOW2: return fragment_color<FS_SHADOW2>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    case FS_OCCLUSION2: return fragment_color<FS_OCCLUSION2>(u, tx, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
     default: return 0;
     }
+}
+
+struct VaryPair {
+    const float *a, *b;
+    f2 operator()(int k) const { return mk2(a[k], b[k]); }
+};
+
+uint64_t g_pair_fast = 0, g_pair_plain = 0;  // how often the two-pixel closures' guard let the fast form stand
+
+// The kernel's use of the two-pixel closures: both pixels together; if either survivor left the guarded
+// range (`plain` stays true) the caller runs the plain closure for both.
+template <int FS>
+void fs_pair(const DevUniforms &u, const DevTextures &tx, const float *va, const float *vb, const Bary2 &bar, f2 uu, f2 vv,
+             uint32_t &ca, uint32_t &cb, uint32_t &ea, uint32_t &eb, const bool won[2], bool &plain)
+{
+    VaryPair v = { va, vb };
+    vec3p barp;
+    barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
+    bool bad_a, bad_b;
+    fragment_color_pair<FS>(u, tx, v, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
+    plain = (bad_a && won[0]) || (bad_b && won[1]);
+    (plain ? g_pair_plain : g_pair_fast)++;
+}
+
+bool run_fs_pair(int fs, const DevUniforms &u, const DevTextures &tx, const float *va, const float *vb, const Bary2 &bar,
+                 f2 uu, f2 vv, uint32_t &ca, uint32_t &cb, uint32_t &ea, uint32_t &eb, const bool won[2], bool &plain)
+{
+    if (!has_pair_closure(fs)) return false;
+    switch (fs) {
+    case FS_NORMAL_MAP: fs_pair<FS_NORMAL_MAP>(u, tx, va, vb, bar, uu, vv, ca, cb, ea, eb, won, plain); break;
+    case FS_SPECULAR: fs_pair<FS_SPECULAR>(u, tx, va, vb, bar, uu, vv, ca, cb, ea, eb, won, plain); break;
+    default: fs_pair<FS_DARBOUX>(u, tx, va, vb, bar, uu, vv, ca, cb, ea, eb, won, plain); break;
+    }
+    return true;
 }
 
 }  // namespace
@@ -174,58 +208,114 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                 const RasterRec &r = rast[tri];
                 const int32_t bx0 = imax(r.bx0, tile_x0), bx1 = imin(r.bx1, tile_x0 + TILE_W - 1);
                 const int32_t by0 = imax(r.by0, tile_y0), by1 = imin(r.by1, tile_y0 + TILE_H - 1);
+                // the tile kernel's forms: orientation-normalised edge constants, two pixels per step in
+                // packed arithmetic, the three-way-minimum inside test, compare-only barycentrics
                 const Edge e = edge_setup(r);
-                const Recip rz = recip_of(e.cz);
+                float la0 = e.a0, la1 = e.a1, lb0 = e.b0, lb1 = e.b1, lcz = la0 * lb1 - la1 * lb0, lry = record_recip(r);
+                if (lcz < 0.0f) {
+                    la0 = -la0; la1 = -la1; lb0 = -lb0; lb1 = -lb1;
+                    lcz = -lcz;
+                    lry = -lry;
+                }
+                Edge2 e2;
+                e2.a0 = splat2(la0); e2.a1 = splat2(la1); e2.b0 = splat2(lb0); e2.b1 = splat2(lb1);
+                e2.cz = splat2(lcz);
+                e2.y = splat2(lry);
                 for (int32_t py = by0; py <= by1; py++)
-                    for (int32_t px = bx0; px <= bx1; px++) {
-                        float cx, cy;
-                        edge_cross(e, px, py, cx, cy);
-                        if (!covers(cx, cy, e.cz)) continue;
-                        const vec3 bar = barycentric_by(cx, cy, rz);
-                        const float z = dot3(bar, make3(r.z0, r.z1, r.z2));
-                        Key &cur = key[(size_t)(py - tile_y0) * TILE_W + (px - tile_x0)];
-                        bool win = z > cur.z;
-                        if (z == cur.z) {
-                            if (cur.slot1 == 0u)
-                                win = depth;
-                            else
-                                win = depth ? tri > bin[cur.slot1 - 1u] : tri < bin[cur.slot1 - 1u];
-                        }
-                        if (win) {
-                            cur.z = z;
-                            cur.slot1 = (uint32_t)bi + 1u;
+                    for (int32_t px = bx0; px <= bx1; px += 2) {
+                        const bool second = px + 1 <= bx1;  // the pair's second pixel (px + 1, py)
+                        f2 cx, cy;
+                        edge_cross2(e2, mk2((float)isub(r.x0, px), (float)isub(r.x0, px + 1)), splat2((float)isub(r.y0, py)), cx, cy);
+                        const f2 rest = e2.cz - (cx + cy);
+                        const bool hit[2] = { covers_oriented(cx.x, cy.x, lcz), second && covers_oriented(cx.y, cy.y, lcz) };
+                        (void)rest;
+                        if (!hit[0] && !hit[1]) continue;
+                        const Bary2 bar = barycentric2_for_compare(cx, cy, e2);
+                        const f2 z2 = dot3_2(bar.x, bar.y, bar.z, splat2(r.z0), splat2(r.z1), splat2(r.z2));
+                        for (int h = 0; h < 2; h++) {
+                            if (!hit[h]) continue;
+                            const float z = h ? z2.y : z2.x;
+                            Key &cur = key[(size_t)(py - tile_y0) * TILE_W + (px + h - tile_x0)];
+                            bool win = z > cur.z;
+                            if (z == cur.z) {
+                                if (cur.slot1 == 0u)
+                                    win = depth;
+                                else
+                                    win = depth ? tri > bin[cur.slot1 - 1u] : tri < bin[cur.slot1 - 1u];
+                            }
+                            if (win) {
+                                cur.z = z;
+                                cur.slot1 = (uint32_t)bi + 1u;
+                            }
                         }
                     }
             }
-            // shade + write
+            // shade + write: two pixels at a time ((i, j) and (i + 1, j)), each against its own survivor,
+            // through the kernel's packed forms -- barycentric2, the two-pixel closures with their
+            // range guard and the plain closure as fallback
             for (int32_t j = 0; j < TILE_H; j++)
-                for (int32_t i = 0; i < TILE_W; i++) {
-                    const int32_t px = tile_x0 + i, py = tile_y0 + j;
-                    if (!(px < (int32_t)W && py >= f.band_y0 && py < f.band_y1)) continue;
-                    const uint32_t s1 = key[(size_t)j * TILE_W + i].slot1;
-                    const bool won = s1 != 0u;
-                    if (!won && !fresh) continue;
-                    float zout = bits_f32(TR_F32_MIN_BITS);
-                    uint32_t rgb = 0, tri = 0xFFFFFFFFu;
-                    if (won) {
-                        tri = bin[s1 - 1u];
-                        const RasterRec &r = rast[tri];
-                        const Edge e = edge_setup(r);
-                        float cx, cy;
-                        edge_cross(e, px, py, cx, cy);
-                        const vec3 bar = barycentric(cx, cy, e.cz);
-                        zout = dot3(bar, make3(r.z0, r.z1, r.z2));
-                        if (!depth)
-                            rgb = run_fs(p.fs, du, tx, &vary[(size_t)tri * VARY_STRIDE], bar, (uint32_t)px,
-                                         (uint32_t)py, zout, shadow, W, H, err);
+                for (int32_t i = 0; i < TILE_W; i += 2) {
+                    const int32_t py = tile_y0 + j;
+                    bool live[2], won[2];
+                    uint32_t tri[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, rgb[2] = { 0u, 0u };
+                    float zout[2] = { bits_f32(TR_F32_MIN_BITS), bits_f32(TR_F32_MIN_BITS) };
+                    const RasterRec *rr[2];
+                    for (int h = 0; h < 2; h++) {
+                        const int32_t px = tile_x0 + i + h;
+                        live[h] = px < (int32_t)W && py >= f.band_y0 && py < f.band_y1;
+                        const uint32_t s1 = live[h] ? key[(size_t)j * TILE_W + i + h].slot1 : 0u;
+                        won[h] = s1 != 0u;
+                        tri[h] = won[h] ? bin[s1 - 1u] : 0xFFFFFFFFu;
+                        rr[h] = &rast[won[h] ? tri[h] : (bin.empty() ? 0u : bin[0])];  // lanes without a survivor run on some record
                     }
-                    target[(size_t)py * W + px] = zout;
-                    if (!depth) {
-                        uint8_t *o = fb + ((size_t)(H - 1 - py) * W + px) * 3;
-                        o[0] = rgb & 0xFF;
-                        o[1] = (rgb >> 8) & 0xFF;
-                        o[2] = (rgb >> 16) & 0xFF;
-                        if (winner) winner[(size_t)py * W + px] = tri;
+                    if ((won[0] || won[1]) && !rast.empty()) {
+                        const Edge ea = edge_setup(*rr[0]), eb = edge_setup(*rr[1]);
+                        Edge2 e2;
+                        e2.a0 = mk2(ea.a0, eb.a0); e2.a1 = mk2(ea.a1, eb.a1); e2.b0 = mk2(ea.b0, eb.b0); e2.b1 = mk2(ea.b1, eb.b1);
+                        e2.cz = e2.a0 * e2.b1 - e2.a1 * e2.b0;
+                        e2.y = mk2(record_recip(*rr[0]), record_recip(*rr[1]));
+                        const int32_t pxa = tile_x0 + i, pxb = pxa + 1;
+                        f2 cx, cy;
+                        edge_cross2(e2, mk2((float)isub(rr[0]->x0, pxa), (float)isub(rr[1]->x0, pxb)),
+                                    mk2((float)isub(rr[0]->y0, py), (float)isub(rr[1]->y0, py)), cx, cy);
+                        const Bary2 bar = barycentric2(cx, cy, e2);
+                        const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(rr[0]->z0, rr[1]->z0), mk2(rr[0]->z1, rr[1]->z1),
+                                            mk2(rr[0]->z2, rr[1]->z2));
+                        const float *va = &vary[(size_t)(won[0] ? tri[0] : 0u) * VARY_STRIDE];
+                        const float *vb = &vary[(size_t)(won[1] ? tri[1] : 0u) * VARY_STRIDE];
+                        uint32_t ca = 0, cb = 0, ea_ = 0, eb_ = 0;
+                        if (!depth) {
+                            f2 uu = mk2(va[0], vb[0]) * bar.x, vv = mk2(va[1], vb[1]) * bar.x;
+                            uu = mk2(va[2], vb[2]) * bar.y + uu;
+                            vv = mk2(va[3], vb[3]) * bar.y + vv;
+                            uu = mk2(va[4], vb[4]) * bar.z + uu;
+                            vv = mk2(va[5], vb[5]) * bar.z + vv;
+                            bool plain = true;
+                            if (run_fs_pair(p.fs, du, tx, va, vb, bar, uu, vv, ca, cb, ea_, eb_, won, plain)) {}
+                            if (plain) {
+                                ea_ = eb_ = 0;
+                                if (won[0])
+                                    ca = run_fs_color(p.fs, du, tx, va, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x,
+                                                      (uint32_t)pxa, (uint32_t)py, z.x, shadow, W, H, ea_);
+                                if (won[1])
+                                    cb = run_fs_color(p.fs, du, tx, vb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y,
+                                                      (uint32_t)pxb, (uint32_t)py, z.y, shadow, W, H, eb_);
+                            }
+                        }
+                        if (won[0]) { zout[0] = z.x; rgb[0] = ca; err |= ea_; }
+                        if (won[1]) { zout[1] = z.y; rgb[1] = cb; err |= eb_; }
+                    }
+                    for (int h = 0; h < 2; h++) {
+                        const int32_t px = tile_x0 + i + h;
+                        if (!live[h] || (!won[h] && !fresh)) continue;
+                        target[(size_t)py * W + px] = zout[h];
+                        if (!depth) {
+                            uint8_t *o = fb + ((size_t)(H - 1 - py) * W + px) * 3;
+                            o[0] = rgb[h] & 0xFF;
+                            o[1] = (rgb[h] >> 8) & 0xFF;
+                            o[2] = (rgb[h] >> 16) & 0xFF;
+                            if (winner) winner[(size_t)py * W + px] = won[h] ? tri[h] : 0xFFFFFFFFu;
+                        }
                     }
                 }
         }
@@ -243,22 +333,26 @@ extern "C" int tr_emul_covers(const int32_t raster[6], int32_t px, int32_t py, f
     r.x0 = raster[0]; r.y0 = raster[1]; r.x1 = raster[2]; r.y1 = raster[3]; r.x2 = raster[4]; r.y2 = raster[5];
     const Edge e = edge_setup(r);
     if (fabsf(e.cz) < 1.0f) return -1;  // degenerate: never drawn
-    float cx, cy;
-    edge_cross(e, px, py, cx, cy);
-    const vec3 b = barycentric(cx, cy, e.cz);
-    bar_out[0] = b.x; bar_out[1] = b.y; bar_out[2] = b.z;
-    // bit 1: the tile kernel's orientation-normalised form of the same test
-    Edge n = e;
-    if (n.cz < 0.0f) {
+    // the shading phase's barycentrics: exact quotients through the record's reciprocal
+    Edge2 e2;
+    e2.a0 = splat2(e.a0); e2.a1 = splat2(e.a1); e2.b0 = splat2(e.b0); e2.b1 = splat2(e.b1);
+    e2.cz = splat2(e.cz);
+    e2.y = splat2(record_recip(r));
+    f2 cx, cy;
+    edge_cross2(e2, splat2((float)isub(r.x0, px)), splat2((float)isub(r.y0, py)), cx, cy);
+    const Bary2 b = barycentric2(cx, cy, e2);
+    bar_out[0] = b.x.x; bar_out[1] = b.y.x; bar_out[2] = b.z.y;
+    // the coverage phase's inside test on the orientation-normalised polygon
+    Edge2 n = e2;
+    float ncz = e.cz;
+    if (ncz < 0.0f) {
         n.a0 = -n.a0; n.a1 = -n.a1; n.b0 = -n.b0; n.b1 = -n.b1;
-        n.cz = -n.cz;
+        ncz = -ncz;
     }
-    float nx, ny;
-    edge_cross(n, px, py, nx, ny);
-    return (covers(cx, cy, e.cz) ? 1 : 0) | (covers_oriented(nx, ny, n.cz) ? 2 : 0);
+    f2 nx, ny;
+    edge_cross2(n, splat2((float)isub(r.x0, px)), splat2((float)isub(r.y0, py)), nx, ny);
+    return covers_oriented(nx.x, ny.y, ncz) ? 3 : 0;
 }
-
-extern "C" uint32_t tr_emul_depth_order_key(float z) { return depth_order_key(z); }
 
 // the specular closure's powf (tr_powf.h) for n argument pairs; returns TR_POWF_EXACT
 extern "C" int tr_emul_powf(const float *x, const float *y, float *out, uint32_t n)
@@ -267,5 +361,31 @@ extern "C" int tr_emul_powf(const float *x, const float *y, float *out, uint32_t
     return TR_POWF_EXACT;
 }
 
-// x / d through the shared-reciprocal division of tr_math.h
-extern "C" float tr_emul_div_by(float x, float d) { return div_by(x, recip_of(d)); }
+// x / d through the shared-reciprocal forms: which = 0 div_by (coverage / barycentrics: keeps the sign of
+// a zero numerator), 1 div_by2_nonzero with y = rcp2(d) (the two-pixel closures)
+extern "C" void tr_emul_div(int which, const float *x, const float *d, float *out, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++)
+        out[i] = which == 0 ? div_by(x[i], recip_of(d[i]))
+                            : div_by2_nonzero(mk2(x[i], x[i]), mk2(d[i], d[i]), rcp2(mk2(d[i], d[i]))).y;
+}
+
+// decode_normal for two texels at once against the plain form; returns the number of differing components
+extern "C" uint32_t tr_emul_decode_normal_mismatches(uint32_t first, uint32_t count)
+{
+    uint32_t bad = 0;
+    for (uint32_t t = first; t < first + count; t++) {
+        const uint32_t other = (t * 2654435761u) & 0xFFFFFFu;
+        const vec3p p = decode_normal_p(t, other);
+        const vec3 a = decode_normal(t), b = decode_normal(other);
+        bad += memcmp(&p.x.x, &a.x, 4) != 0 || memcmp(&p.y.x, &a.y, 4) != 0 || memcmp(&p.z.x, &a.z, 4) != 0 ||
+               memcmp(&p.x.y, &b.x, 4) != 0 || memcmp(&p.y.y, &b.y, 4) != 0 || memcmp(&p.z.y, &b.z, 4) != 0;
+    }
+    return bad;
+}
+
+extern "C" void tr_emul_pair_counts(uint64_t out[2])
+{
+    out[0] = g_pair_fast;
+    out[1] = g_pair_plain;
+}

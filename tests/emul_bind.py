@@ -18,10 +18,12 @@ def lib():
         L.tr_emul_render.restype = C.c_uint32
         L.tr_emul_covers.restype = C.c_int
         L.tr_emul_covers.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_float)]
-        L.tr_emul_depth_order_key.restype = C.c_uint32
-        L.tr_emul_depth_order_key.argtypes = [C.c_float]
-        L.tr_emul_div_by.restype = C.c_float
-        L.tr_emul_div_by.argtypes = [C.c_float, C.c_float]
+        L.tr_emul_div.restype = None
+        L.tr_emul_div.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.tr_emul_decode_normal_mismatches.restype = C.c_uint32
+        L.tr_emul_decode_normal_mismatches.argtypes = [C.c_uint32, C.c_uint32]
+        L.tr_emul_pair_counts.restype = None
+        L.tr_emul_pair_counts.argtypes = [C.POINTER(C.c_uint64)]
         L.tr_emul_powf.restype = C.c_int
         L.tr_emul_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _lib = L

@@ -2,8 +2,11 @@
   * division-free inside tests (tr_shaders.h `covers`, and `covers_oriented`: the orientation-
     normalised three-way-minimum form of the tile kernel) vs the reference's sign tests on the
     divided barycentric coordinates (scene.rs:192-196, 245) as restated by the oracle;
-  * shared-reciprocal division (tr_math.h `div_by`) vs IEEE '/';
-  * depth_order_key is monotone and folds -0.0 onto +0.0."""
+  * shared-reciprocal division vs IEEE '/': `div_by` (tr_math.h) on the coverage loop's integer-valued
+    operands and `div_by2_nonzero` (tr_pk.h) on general operands inside the two-pixel closures' guard
+    range; decode_normal's two-texel form for all 2^24 texels.
+On the host rcp2 / sqrt2 are '/' and sqrtf; their device forms are checked exhaustively on the GPU
+(tests/test_gpu_parity.py::test_pair_rcp_sqrt_exhaustive)."""
 import ctypes as C
 
 import numpy as np
@@ -26,7 +29,8 @@ def _check_triangles(tris, pts):
             if got < 0:   # degenerate: the oracle reports (-1, 1, 1)
                 assert list(bo) == [-1.0, 1.0, 1.0]
                 continue
-            # bit 0: `covers`; bit 1: `covers_oriented`, the form the tile kernel evaluates
+            # both bits: `covers_oriented` on the orientation-normalised polygon, the form the tile kernel
+            # evaluates; the barycentrics are the shading phase's (`barycentric2`)
             assert (got & 1) == ref_inside and (got >> 1) == ref_inside, (list(t), px, py, list(bo), got)
             assert np.array_equal(np.array(bo, np.float32).view(np.uint32), np.array(be, np.float32).view(np.uint32))
             n_cov += got & 1
@@ -60,28 +64,71 @@ def test_covers_matches_divided_sign_tests_large_coordinates():
     assert _check_triangles(tris, pts) > 1000
 
 
+def _div(which, x, d):
+    x = np.ascontiguousarray(x, np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    out = np.empty_like(x)
+    E.lib().tr_emul_div(which, x.ctypes.data, d.ctypes.data, out.ctypes.data, x.size)
+    return out
+
+
 def test_shared_reciprocal_division_is_correctly_rounded():
-    L = E.lib()
+    """div_by (coverage / barycentrics): integer-valued operands, |d| >= 1, zero numerators keep their sign."""
     rng = np.random.default_rng(9)
-    n = 200000
-    # coverage operands: integer valued, |d| >= 1; include all-ones mantissas and near-midpoint quotients
+    n = 2000000
     d = np.concatenate([rng.integers(1, 1 << 26, n // 2).astype(np.float32),
                         (rng.integers(1, 1 << 24, n // 4) * 2 - 1).astype(np.float32) * np.float32(1 << 10),
                         np.float32(2.0) ** rng.integers(0, 40, n // 4) * np.float32(1.9999999)])
     d = np.trunc(d) * rng.choice([-1.0, 1.0], d.size).astype(np.float32)
     x = np.trunc((rng.standard_normal(d.size) * 2.0 ** rng.integers(0, 40, d.size)).astype(np.float32))
+    x[::97] = 0.0
+    x[1::97] = -0.0
     want = (x / d).astype(np.float32)
-    got = np.array([L.tr_emul_div_by(float(a), float(b)) for a, b in zip(x, d)], np.float32)
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(_div(0, x, d).view(np.uint32), want.view(np.uint32))
 
 
-def test_depth_order_key():
-    L = E.lib()
-    vals = np.array([-np.inf, -3.4028235e38, -1e10, -1.0, -1e-30, -0.0, 0.0, 1e-30, 1.0, 254.5, 1e10, np.inf], np.float32)
-    keys = [L.tr_emul_depth_order_key(float(v)) for v in vals]
-    assert keys[5] == keys[6]                       # -0.0 == +0.0 for `z <= zbuf`
-    ks = keys[:5] + keys[6:]
-    assert all(a < b for a, b in zip(ks, ks[1:]))
+def test_pair_closure_division_on_general_operands():
+    """div_by2_nonzero (the two-pixel closures: normalisations, the 3x3 inverse): ANY f32 operands inside
+    the guard range 2^-40 <= |x|, |d| <= 2^41, x != 0 -- not only integers.  1.1e8 pairs, three
+    quarters of them adversarial: quotients placed within a few ulp of a rounding boundary
+    (x = RN(d * m) for m a float or a midpoint between two floats, nudged by -2..2 ulp), divisors with
+    all-ones or single-bit significands.  Must equal IEEE x / d bit for bit."""
+    rng = np.random.default_rng(21)
+    chunk, total = 4000000, 0
+
+    def mant(k):   # random significands in [1, 2), a share of them all-ones / single-bit
+        m = (1.0 + rng.integers(0, 1 << 23, k) * 2.0 ** -23)
+        sel = rng.integers(0, 8, k)
+        m = np.where(sel == 0, 2.0 - 2.0 ** -23 * rng.integers(1, 4, k), m)
+        m = np.where(sel == 1, 1.0 + 2.0 ** -rng.integers(1, 24, k).astype(np.float64), m)
+        return m
+
+    for it in range(30):
+        d = (mant(chunk) * 2.0 ** rng.integers(-40, 41, chunk) * rng.choice([-1.0, 1.0], chunk)).astype(np.float32)
+        if it % 4 == 3:   # every fourth chunk: unrelated random operands
+            x = (mant(chunk) * 2.0 ** rng.integers(-40, 41, chunk) * rng.choice([-1.0, 1.0], chunk)).astype(np.float32)
+        else:
+            q = (mant(chunk) * 2.0 ** rng.integers(-20, 21, chunk)).astype(np.float32)
+            # a quotient target: q itself or the midpoint between q and its successor; x = RN(target * d) +- ulps
+            mid = rng.integers(0, 2, chunk).astype(bool)
+            target = np.where(mid, q.astype(np.float64) * (1.0 + 2.0 ** -24), q.astype(np.float64))
+            x = (target * d.astype(np.float64)).astype(np.float32)
+            x = (x.view(np.int32) + rng.integers(-2, 3, chunk).astype(np.int32)).view(np.float32)
+        ok = (np.abs(x) >= 2.0 ** -40) & (np.abs(x) <= 2.0 ** 41) & np.isfinite(x)
+        x, d = x[ok], d[ok]
+        with np.errstate(all="ignore"):
+            want = (x / d).astype(np.float32)   # numpy float32 division is IEEE
+        got = _div(1, x, d)
+        bad = got.view(np.uint32) != want.view(np.uint32)
+        assert not bad.any(), (x[bad][:3], d[bad][:3], got[bad][:3], want[bad][:3])
+        total += int(x.size)
+    assert total >= 100000000
+
+
+def test_decode_normal_pair_form_all_texels():
+    """decode_normal for two texels at once (channel / 255 through the constant's reciprocal, shared
+    reciprocal of the norm) against the plain form for every one of the 2^24 rgb values."""
+    assert E.lib().tr_emul_decode_normal_mismatches(0, 1 << 24) == 0
 
 
 def test_powf_reproduces_the_host_libm():

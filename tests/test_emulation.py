@@ -42,7 +42,17 @@ def test_synthetic(synthetic, pipe):
 @pytest.mark.parametrize("pipe", PIPES)
 def test_diablo_800(diablo, pipe):
     mesh, texs = diablo
+    import ctypes as C
+    before = (C.c_uint64 * 2)()
+    E.lib().tr_emul_pair_counts(before)
     assert_same(*run_both(800, 800, mesh, texs, pipe, 0.7, -1.1), pipe)
+    if pipe in ("normal_map", "specular", "darboux"):
+        # the two-pixel closures really ran in their fast form (a guard that always failed would leave
+        # the comparison above vacuous): more than nine pixel pairs in ten on this model
+        after = (C.c_uint64 * 2)()
+        E.lib().tr_emul_pair_counts(after)
+        fast, plain = after[0] - before[0], after[1] - before[1]
+        assert fast > 9 * plain and fast > 10000, (fast, plain)
 
 
 def test_african_head_default(african_head):

@@ -601,3 +601,19 @@ def test_caller_stream_consumes_frames_without_sync(small_synthetic):
         assert cpu.render() == 0
         assert np.array_equal(kept[f].cpu().numpy().reshape(Hh, W, 3), cpu.get_frame_buffer()), "frame %d" % f
     gpu.close()
+
+
+def test_pair_rcp_sqrt_exhaustive(built):
+    """rcp2 / sqrt2 (tr_pk.h: v_rcp_f32 / v_rsq_f32 + fused residual corrections in packed arithmetic) against the
+    compiler's correctly rounded 1.0f / x and sqrtf for EVERY f32 of the ranges the two-pixel closures'
+    guard admits (|d| in [2^-40, 2^41] -> exponents -42..42 tested; sums of squares in [2^-80, 2^82] ->
+    -84..84): 7.1e8 + 1.4e9 arguments, none may differ."""
+    import ctypes as C
+    import tiny_renderer_amd as T
+    L = T.load_library()
+    for which, lo, hi in ((0, -42, 42), (1, -84, 84)):
+        nt, nb = C.c_uint64(), C.c_uint64()
+        bits = (C.c_uint32 * 16)()
+        T._lib.check(L.tr_selftest_device_unary(0, which, lo, hi, C.byref(nt), C.byref(nb), bits))
+        assert nt.value == (hi - lo + 1) << 23
+        assert nb.value == 0, [hex(b) for b in bits if b]

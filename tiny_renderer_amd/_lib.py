@@ -88,6 +88,8 @@ SYMBOLS = {
     "tr_scene_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int]),
     "tr_scene_profile_frame_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tr_selftest_device_math": (C.c_int, [C.c_int, _FP, _FP, C.c_uint32] + [C.c_void_p] * 5),
+    "tr_selftest_device_unary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "tr_pipeline_count": (C.c_int, []),
     "tr_pipeline_name": (C.c_char_p, [C.c_int]),
     "tr_prepare_uniforms": (C.c_int, [C.c_int, C.POINTER(Uniforms), C.c_uint32, C.c_uint32,

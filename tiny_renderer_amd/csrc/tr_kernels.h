@@ -22,6 +22,9 @@ int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
                     uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st);
+// rcp2 (which = 0) / sqrt2 (1) of tr_pk.h against '/' and sqrtf for the f32 bit patterns [first, first + count)
+int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned long long *n_bad, uint32_t *bad_bits,
+                          hipStream_t st);
 // 1 when the specular closure's powf reproduces the host libm's bit for bit (tr_powf.h)
 int specular_is_exact();
 int launch_depth_view(const float *src, uint8_t *dst, uint32_t W, uint32_t H, hipStream_t st);

@@ -327,8 +327,32 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
     return __builtin_amdgcn_readlane((int)v, (int)lane);
 }
 
+// Waves per SIMD each k_tile variant is compiled for (= its VGPR budget: 8 -> 64, 6 -> 80, 5 -> 96,
+// 4 -> 128).  Six for the light closures (walked both ways in round 1: five lost 5 %, seven lost 9 %);
+// the closures that run two pixels' normalisations and a 3x3 inverse in packed registers need more
+// room than that leaves them (80 VGPRs: 30-50 spilled dwords per lane, specular 446 -> 559 us on the
+// x64 grid): normal_map and specular five waves (96), darboux four (128) -- profiles/r02_notes.md.
+#ifndef TR_WPE_SPECULAR
+#define TR_WPE_SPECULAR 5
+#endif
+#ifndef TR_WPE_DARBOUX
+#define TR_WPE_DARBOUX 4
+#endif
+#ifndef TR_WPE_NORMAL_MAP
+#define TR_WPE_NORMAL_MAP 5
+#endif
+constexpr int tile_waves_per_eu(int fs, int tile_waves)
+{
+    const int want = fs == FS_DARBOUX ? TR_WPE_DARBOUX : fs == FS_SPECULAR ? TR_WPE_SPECULAR
+                     : fs == FS_NORMAL_MAP ? TR_WPE_NORMAL_MAP : 6;
+    // sixteen waves per tile: a workgroup brings four waves to every SIMD, so 8 (two workgroups per
+    // CU) or 4 (one) are the only useful budgets
+    if (tile_waves == 16) return want >= 6 ? 8 : 4;
+    return want;
+}
+
 template <int FS, int TILE_WAVES>
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(FS == FS_DARBOUX ? 5 : TILE_WAVES == 16 ? 8 : 6, FS == FS_DARBOUX ? 5 : TILE_WAVES == 16 ? 8 : 6))) void k_tile(TileArgs a)
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES), tile_waves_per_eu(FS, TILE_WAVES)))) void k_tile(TileArgs a)
 {
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     static_assert(STRIP_ROWS % 4 == 0, "a shading step covers four rows");
     constexpr bool DEPTH = (FS == FS_DEPTH);
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    constexpr int NMAX = LDS_REC_BYTES / (P * 16);  // records resident in LDS
+    constexpr int NMAX = lds_rec_bytes(TILE_WAVES) / (P * 16);  // records resident in LDS
 
     // Per pixel: .x = z of the best fragment so far (f32 bits; compared as floats, so -0.0 and
     // +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what the
@@ -690,9 +714,35 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                         return fragment_color<FS>(a.u, a.tex, v, b, u_, v_, (uint32_t)px, (uint32_t)py_, z_, a.shadow,
                                                   (uint32_t)W, (uint32_t)H, e_);
                     };
-                    ca = closure(qa, ra, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, py[0], z.x, ea);
-                    __builtin_amdgcn_sched_barrier(0);
-                    cb = closure(qb, rb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, py[1], z.y, eb);
+                    bool plain = true;
+                    if (has_pair_closure(FS)) {
+                        // both pixels through the closure together in packed arithmetic with shared
+                        // reciprocals (tr_shaders.h, fragment_color_pair); a pixel whose operands leave the
+                        // range that form is proven on takes the plain closure below (rare: exact zeros
+                        // among the normalised components, or a degenerate basis)
+                        auto vary2 = [&](int k) -> f2 {
+                            const int i = k < 2 ? 3 : (k + 14) / 4, c = k < 2 ? k + 2 : (k + 14) % 4;
+                            const uint4 pa = i < TOP ? qa[i] : ra[i], pb = i < TOP ? qb[i] : rb[i];
+                            const uint32_t wa = c == 0 ? pa.x : c == 1 ? pa.y : c == 2 ? pa.z : pa.w;
+                            const uint32_t wb = c == 0 ? pb.x : c == 1 ? pb.y : c == 2 ? pb.z : pb.w;
+                            return mk2(__uint_as_float(wa), __uint_as_float(wb));
+                        };
+                        bool bad_a, bad_b;
+                        uint32_t fa = 0u, fb_ = 0u;
+                        vec3p barp;
+                        barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
+                        fragment_color_pair<FS>(a.u, a.tex, vary2, barp, uu, vv, ca, cb, fa, fb_, bad_a, bad_b);
+                        plain = __any((bad_a && won[0]) || (bad_b && won[1]));
+                        if (!plain) {
+                            ea = fa;
+                            eb = fb_;
+                        }
+                    }
+                    if (plain) {
+                        ca = closure(qa, ra, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, py[0], z.x, ea);
+                        __builtin_amdgcn_sched_barrier(0);
+                        cb = closure(qb, rb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, py[1], z.y, eb);
+                    }
                 }
             }
             uint32_t err = 0u;
@@ -824,7 +874,40 @@ __global__ __launch_bounds__(256) void k_selftest(const float *x, const float *d
     out_div_ref[i] = x[i] / d[i];
 }
 
+// tr_selftest_device_unary: rcp2 / sqrt2 (tr_pk.h) against the compiler's correctly rounded
+// 1.0f / x and sqrtf for every f32 whose bits lie in [first, first + count).
+__global__ __launch_bounds__(256) void k_selftest_unary(int which, uint32_t first, uint64_t count,
+                                                        unsigned long long *n_bad, uint32_t *bad_bits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float x = __uint_as_float(first + (uint32_t)i);
+        float got, want;
+        if (which == 0) {
+            got = rcp2(mk2(x, -x)).x;
+            want = 1.0f / x;
+            if (__float_as_uint(rcp2(mk2(x, -x)).y) != __float_as_uint(-1.0f / x)) got = __uint_as_float(~__float_as_uint(want));
+        } else {
+            got = sqrt2(mk2(x, x)).y;
+            want = sqrtf(x);
+        }
+        if (__float_as_uint(got) != __float_as_uint(want)) {
+            const unsigned long long k = atomicAdd(n_bad, 1ull);
+            if (k < 16ull) bad_bits[k] = __float_as_uint(x);
+        }
+    }
+}
+
 }  // namespace
+
+int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned long long *n_bad, uint32_t *bad_bits,
+                          hipStream_t st)
+{
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_selftest_unary, dim3(4096), dim3(256), 0, st, which, first, count, n_bad, bad_bits);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
 
 // -----------------------------------------------------------------------------------------
 // Launchers

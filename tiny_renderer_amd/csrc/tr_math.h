@@ -193,15 +193,6 @@ TR_HD float bits_f32(uint32_t u)
     return c.f;
 }
 
-// Monotone map f32 -> u32 (total order of finite floats and infinities); -0.0 is folded onto
-// +0.0 first because the reference's `z <= zbuf` treats them as equal.
-TR_HD uint32_t depth_order_key(float z)
-{
-    uint32_t b = f32_bits(z);
-    if (b == 0x80000000u) b = 0u;
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
 #define TR_F32_MIN_BITS 0xFF7FFFFFu /* f32::MIN */
 
 }  // namespace tr

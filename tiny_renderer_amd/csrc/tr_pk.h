@@ -42,26 +42,49 @@ TR_HD f2 fma2(f2 a, f2 b, f2 c) { return mk2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y,
 
 TR_HD f2 splat2(float a) { return mk2(a, a); }
 
-// div_by (tr_math.h) for two numerators; d and y = RN(1/d) may differ per component.
-TR_HD f2 div_by2(f2 x, f2 d, f2 y)
-{
-    const f2 q0 = x * y;
-    f2 e = fma2(-q0, d, x);
-    f2 q = fma2(e, y, q0);
-    e = fma2(-q, d, x);
-    q = fma2(e, y, q);
-    return mk2(x.x == 0.0f ? q0.x : q.x, x.y == 0.0f ? q0.y : q.y);
-}
-
 // The signed-zero repair of div_by as one bit operation: q0 = x * y always carries the sign of the
 // quotient (no underflow here: |x| >= 1 or x = 0, |y| >= 2^-62), and the corrected q differs from it
 // in sign only when x is a zero.
 TR_HD f2 quotient_sign_from(f2 q, f2 q0) { return mk2(copysignf(q.x, q0.x), copysignf(q.y, q0.y)); }
 
-// The same without the signed-zero repair: a quotient of a -0 numerator may come out as +0.
-// For consumers that only compare the result (or sums built from it) with IEEE ordering, where
-// +0 and -0 are the same value -- the coverage loop's depth test.
-TR_HD f2 div_by2_unsigned_zero(f2 x, f2 d, f2 y)
+// ---------------------------------------------------------------------------------------------
+// Correctly rounded 1/d and sqrt(s) for two values at once.  The device forms start from the
+// hardware's 1-ulp estimates (v_rcp_f32, v_rsq_f32) and finish with fused residual corrections in
+// packed arithmetic -- 2 + 4 and 2 + 7 instructions per PAIR instead of the 2 x 11 and 2 x 12 of the
+// compiler's general-purpose expansions (which also scale for denormal and huge operands).  Valid
+// for normal operands well inside the exponent range: |d| in [2^-42, 2^42], s in [2^-82, 2^82] --
+// callers guard the range (tr_shaders.h, PairGuard) and fall back to '/' and sqrtf outside it.
+// Proof: exhaustive on the device -- tr_selftest_device_unary compares every f32 of those ranges
+// (1.4e9 + 2.8e9 values) with the compiler's correctly rounded '/' and sqrtf
+// (tests/test_gpu_parity.py::test_pair_rcp_sqrt_exhaustive).  On the host they ARE '/' and sqrtf.
+#if defined(__HIP_DEVICE_COMPILE__)
+TR_HD f2 rcp2(f2 d)
+{
+    f2 y = mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+    f2 e = fma2(-d, y, mk2(1.0f, 1.0f));
+    y = fma2(e, y, y);
+    e = fma2(-d, y, mk2(1.0f, 1.0f));
+    return fma2(e, y, y);
+}
+TR_HD f2 sqrt2(f2 s)
+{
+    const f2 r = mk2(__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y));
+    f2 g = s * r, h = r * mk2(0.5f, 0.5f);
+    const f2 e = fma2(-h, g, mk2(0.5f, 0.5f));
+    g = fma2(g, e, g);
+    h = fma2(h, e, h);
+    const f2 d = fma2(-g, g, s);
+    return fma2(d, h, g);
+}
+#else
+TR_HD f2 rcp2(f2 d) { return mk2(1.0f / d.x, 1.0f / d.y); }
+TR_HD f2 sqrt2(f2 s) { return mk2(sqrtf(s.x), sqrtf(s.y)); }
+#endif
+
+// x / d for operands inside the guarded range and x != 0, y = rcp2(d): div_by2 without the signed-zero
+// repair (Markstein: y = RN(1/d), q faithful after the first correction, exact residuals because
+// |x| >= 2^-40 keeps them far above the subnormal grid).
+TR_HD f2 div_by2_nonzero(f2 x, f2 d, f2 y)
 {
     const f2 q0 = x * y;
     f2 e = fma2(-q0, d, x);

@@ -894,6 +894,36 @@ int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t
     return st;
 }
 
+int tr_selftest_device_unary(int device, int which, int exp_lo, int exp_hi, uint64_t *n_tested, uint64_t *n_bad,
+                             uint32_t bad_bits[16])
+{
+    if (!n_tested || !n_bad || !bad_bits || (which != 0 && which != 1) || exp_lo < -126 || exp_hi > 127 || exp_lo > exp_hi)
+        return tr::fail(TR_E_INVALID, "bad argument");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    unsigned long long *d_n = nullptr;
+    uint32_t *d_bits = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_n, 8));
+    HIP_TRY(hipMalloc((void **)&d_bits, 64));
+    HIP_TRY(hipMemset(d_n, 0, 8));
+    HIP_TRY(hipMemset(d_bits, 0, 64));
+    // every f32 with exponent in [exp_lo, exp_hi]: one contiguous range of bit patterns (positive
+    // values; the reciprocal kernel checks -x beside x)
+    const uint32_t first = (uint32_t)(exp_lo + 127) << 23;
+    const uint64_t count = (uint64_t)(exp_hi - exp_lo + 1) << 23;
+    int rc = launch_selftest_unary(which, first, count, d_n, d_bits, nullptr);
+    int st = TR_OK;
+    if (rc || hipDeviceSynchronize() != hipSuccess) st = tr::fail(TR_E_HIP, "self-test kernel failed");
+    unsigned long long nb = 0;
+    if (st == TR_OK && (hipMemcpy(&nb, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(bad_bits, d_bits, 64, hipMemcpyDeviceToHost) != hipSuccess))
+        st = tr::fail(TR_E_HIP, "download failed");
+    (void)hipFree(d_n);
+    (void)hipFree(d_bits);
+    *n_tested = count;
+    *n_bad = nb;
+    return st;
+}
+
 int tr_pipeline_count(void) { return P_COUNT; }
 
 const char *tr_pipeline_name(int i) { return (i >= 0 && i < P_COUNT) ? kPipelines[i].name : nullptr; }

@@ -196,51 +196,22 @@ TR_HD void mark_rejected(RasterRec &r)
 // Coverage
 // ---------------------------------------------------------------------------------------------
 
-// x and y of the raw cross product at pixel (px, py); z is Edge::cz.
-TR_HD void edge_cross(const Edge &e, int32_t px, int32_t py, float &cx, float &cy)
-{
-    float a2 = (float)isub(e.x0, px);
-    float b2 = (float)isub(e.y0, py);
-    cx = e.a1 * b2 - a2 * e.b1;
-    cy = a2 * e.b0 - e.a0 * b2;
-}
-
 // The reference's inside test is `!(bar.x < 0 || bar.y < 0 || bar.z < 0)` on
-// bar = (1 - (cx+cy)/cz, cx/cz, cy/cz) (scene.rs:192-196, 245).  With |cz| >= 1 and cx, cy
-// integer valued (products and differences of i32-valued floats) the three sign tests can be
-// decided without dividing:
+// bar = (1 - (cx+cy)/cz, cx/cz, cy/cz) (scene.rs:192-196, 245), cx / cy / cz the components of the raw
+// cross product of scene.rs:178-187.  With |cz| >= 1 and cx, cy integer valued (products and
+// differences of i32-valued floats) the three sign tests can be decided without dividing:
 //   fl(cx/cz) < 0   <=>  cx != 0 and sign(cx) != sign(cz)   (no underflow is possible);
 //   fl(1 - fl(s/cz)) < 0  <=>  fl(s/cz) > 1  <=>  |s| > |cz| with sign(s) = sign(cz), because for
 //   floats s > cz > 0 the quotient exceeds 1 + 2^-24 and so rounds above 1.
-// tests/test_coverage_math.py checks the equivalence against the dividing form exhaustively on
-// random and adversarial inputs.  Only covered fragments pay for the three IEEE divisions.
-TR_HD bool covers(float cx, float cy, float cz)
-{
-    float s = cx + cy;
-    if (cz > 0.0f) return cx >= 0.0f && cy >= 0.0f && s <= cz;
-    return cx <= 0.0f && cy <= 0.0f && s >= cz;
-}
-
 // The form the tile kernel evaluates (two pixels at a time, packed): the polygon is first
 // orientation-normalised -- a0, a1, b0, b1 negated when cross.z < 0, which negates cross.x and
 // cross.y exactly -- so that cz > 0, and `s <= cz` is taken as cz - s >= 0 (a difference of two
 // floats has the sign of the exact difference; f32 denormals are on), which lets one three-way
-// minimum and one compare decide a pixel.  Checked against `covers` and the dividing form by
-// tests/test_coverage_math.py.
+// minimum and one compare decide a pixel.  Checked against the dividing form (the oracle's
+// to_barycentric_coord + sign tests) by tests/test_coverage_math.py.
 TR_HD bool covers_oriented(float cx, float cy, float cz_positive)
 {
     return fminf(fminf(cx, cy), cz_positive - (cx + cy)) >= 0.0f;
-}
-
-TR_HD vec3 barycentric(float cx, float cy, float cz)
-{
-    return make3(1.0f - (cx + cy) / cz, cx / cz, cy / cz);
-}
-
-// Same values through the shared-reciprocal division (one polygon, many pixels).
-TR_HD vec3 barycentric_by(float cx, float cy, Recip rz)
-{
-    return make3(1.0f - div_by(cx + cy, rz), div_by(cx, rz), div_by(cy, rz));
 }
 
 // RN(1 / cross.z) of a polygon record: computed once per polygon by the setup kernel, carried
@@ -263,11 +234,12 @@ struct Bary2 {
     f2 x, y, z;
 };
 
-// Barycentrics whose zeros may carry the wrong sign (see div_by2_unsigned_zero): good for the
-// depth comparison of the coverage loop, not for values that are stored.
+// Barycentrics whose zeros may carry the wrong sign (the residual corrections turn a -0 / d into +0
+// and the repair is skipped): good for the depth comparison of the coverage loop, where +0 and -0
+// are the same value, not for values that are stored.
 TR_HD Bary2 barycentric2_for_compare(f2 cx, f2 cy, const Edge2 &e)
 {
-    // the three quotients of div_by2_unsigned_zero advanced in lockstep: each step's three
+    // the three shared-reciprocal quotients (div_by, tr_math.h) advanced in lockstep: each step's three
     // operations are independent, so no dependent packed operation issues back to back
     const f2 s = cx + cy;
     const f2 q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
@@ -475,18 +447,217 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
     return 0u;
 }
 
-template <int FS>
-TR_HD uint32_t fragment_stage(const DevUniforms &u, const DevTextures &tex, const float *vary,
-                              vec3 bar, uint32_t x, uint32_t y, float z, const float *shadow,
-                              uint32_t W, uint32_t H, uint32_t &err)
+// ---------------------------------------------------------------------------------------------
+// Fragment stage, two pixels at a time
+// ---------------------------------------------------------------------------------------------
+// The closures that normalise vectors and invert a basis per fragment (normal_map, specular,
+// darboux: shader.rs:439-459, 498-534, 597-655) spend most of their instructions in IEEE divisions
+// and square roots: darboux has 27 of the former and 5 of the latter per fragment, each an 11-12
+// instruction expansion.  The tile kernel shades two pixels per lane; here both go through the
+// closure together in packed arithmetic (one v_pk_* instruction = the same IEEE operation on both
+// pixels, tr_pk.h), the divisions of one normalisation or one inverse share ONE reciprocal
+// (div_by2_nonzero: Markstein's correction, bit-equal to '/'), and reciprocal and square root come
+// from the hardware estimates plus fused corrections (rcp2 / sqrt2, exhaustively equal to '/' and
+// sqrtf on the guarded range).  Every operation keeps the reference's order and rounding; the
+// results are bit-identical BY CONSTRUCTION inside the guarded operand range, and outside it --
+// exact zeros among the numerators, values below 2^-40 or above 2^40, NaN -- the caller runs the
+// plain closure (fragment_color) instead, so the fast path never has to be right there.
+struct vec3p {
+    f2 x, y, z;
+};
+TR_HD vec3p make3p(f2 x, f2 y, f2 z)
 {
-    // uv = vertex_uvs * bar (2x3 gemv)
-    float uu = vary[0] * bar.x, vv = vary[1] * bar.x;
-    uu = vary[2] * bar.y + uu;
-    vv = vary[3] * bar.y + vv;
-    uu = vary[4] * bar.z + uu;
-    vv = vary[5] * bar.z + vv;
-    return fragment_color<FS>(u, tex, vary, bar, uu, vv, x, y, z, shadow, W, H, err);
+    vec3p r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+TR_HD vec3p splat3p(vec3 v) { return make3p(splat2(v.x), splat2(v.y), splat2(v.z)); }
+TR_HD f2 dot3p(vec3p a, vec3p b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// mul_m3_v3 (tr_math.h) for two pixels: column-accumulating gemv
+TR_HD vec3p mul_m3_v3p(vec3p c0, vec3p c1, vec3p c2, vec3p v)
+{
+    vec3p r = make3p(c0.x * v.x, c0.y * v.x, c0.z * v.x);
+    r = make3p(c1.x * v.y + r.x, c1.y * v.y + r.y, c1.z * v.y + r.z);
+    r = make3p(c2.x * v.z + r.x, c2.y * v.z + r.y, c2.z * v.z + r.z);
+    return r;
+}
+
+// Smallest and largest magnitude among the operands of the fast divisions and square roots of one
+// closure invocation, per pixel.  fminf / fmaxf skip NaN: the closures test their result for it.
+constexpr float PAIR_GUARD_LO = 9.094947017729282e-13f;  // 2^-40
+constexpr float PAIR_GUARD_HI = 1099511627776.0f;        // 2^40
+struct PairGuard {
+    f2 lo, hi;
+};
+TR_HD PairGuard guard_init()
+{
+    PairGuard g;
+    g.lo = splat2(1.0f);
+    g.hi = splat2(1.0f);
+    return g;
+}
+TR_HD void guard_add(PairGuard &g, f2 a)
+{
+    g.lo = mk2(fminf(g.lo.x, fabsf(a.x)), fminf(g.lo.y, fabsf(a.y)));
+    g.hi = mk2(fmaxf(g.hi.x, fabsf(a.x)), fmaxf(g.hi.y, fabsf(a.y)));
+}
+TR_HD void guard_add3(PairGuard &g, f2 a, f2 b, f2 c)
+{
+    g.lo = mk2(fminf(fminf(fminf(g.lo.x, fabsf(a.x)), fabsf(b.x)), fabsf(c.x)),
+               fminf(fminf(fminf(g.lo.y, fabsf(a.y)), fabsf(b.y)), fabsf(c.y)));
+    g.hi = mk2(fmaxf(fmaxf(fmaxf(g.hi.x, fabsf(a.x)), fabsf(b.x)), fabsf(c.x)),
+               fmaxf(fmaxf(fmaxf(g.hi.y, fabsf(a.y)), fabsf(b.y)), fabsf(c.y)));
+}
+// true = some operand of this pixel was outside the range the fast forms are proven on
+TR_HD bool guard_bad(const PairGuard &g, int half)
+{
+    const float lo = half ? g.lo.y : g.lo.x, hi = half ? g.hi.y : g.hi.x;
+    return !(lo >= PAIR_GUARD_LO && hi <= PAIR_GUARD_HI);
+}
+
+// normalize3 for two pixels, operands already known to lie in the guarded range and to be non-zero
+TR_HD vec3p normalize3p_in_range(vec3p a)
+{
+    const f2 n = sqrt2(dot3p(a, a));
+    const f2 y = rcp2(n);
+    return make3p(div_by2_nonzero(a.x, n, y), div_by2_nonzero(a.y, n, y), div_by2_nonzero(a.z, n, y));
+}
+// normalize3 for two pixels; the components enter the guard (components in [2^-40, 2^40] put the sum
+// of squares in [2^-80, 2^82] and the norm in [2^-40, 2^41]: inside sqrt2's and rcp2's ranges)
+TR_HD vec3p normalize3p(vec3p a, PairGuard &g)
+{
+    guard_add3(g, a.x, a.y, a.z);
+    return normalize3p_in_range(a);
+}
+
+// decode_normal (util.rs:51-56) for two texels: channel / 255 - 0.5, normalised.  No guard: the
+// channels are integers 0..255 (c / 255 through the constant's reciprocal is checked for all 256,
+// tests/test_coverage_math.py), so every component's magnitude is one of (k + 0.5) / 255, k =
+// 0..127: never zero, within [0.00196, 0.5].
+TR_HD vec3p decode_normal_p(uint32_t pa, uint32_t pb)
+{
+    const f2 d = splat2(255.0f), y = splat2(1.0f / 255.0f), half = splat2(0.5f);
+    const f2 cx = mk2((float)(pa & 0xFFu), (float)(pb & 0xFFu));
+    const f2 cy = mk2((float)((pa >> 8) & 0xFFu), (float)((pb >> 8) & 0xFFu));
+    const f2 cz = mk2((float)((pa >> 16) & 0xFFu), (float)((pb >> 16) & 0xFFu));
+    return normalize3p_in_range(make3p(div_by2_nonzero(cx, d, y) - half, div_by2_nonzero(cy, d, y) - half,
+                                       div_by2_nonzero(cz, d, y) - half));
+}
+
+// transform_normal for two pixels: xyz of it_m * (n, 0) in mul_m4_v4's accumulation order (the w = 0
+// column's products are kept: they can turn a -0 sum into +0), then normalised
+TR_HD vec3p transform_normal_p(const float *m, vec3p n, PairGuard &g)
+{
+    const f2 zero = splat2(0.0f);
+    f2 rx = splat2(m[0]) * n.x, ry = splat2(m[1]) * n.x, rz = splat2(m[2]) * n.x;
+    rx = splat2(m[4]) * n.y + rx;
+    ry = splat2(m[5]) * n.y + ry;
+    rz = splat2(m[6]) * n.y + rz;
+    rx = splat2(m[8]) * n.z + rx;
+    ry = splat2(m[9]) * n.z + ry;
+    rz = splat2(m[10]) * n.z + rz;
+    rx = splat2(m[12]) * zero + rx;
+    ry = splat2(m[13]) * zero + ry;
+    rz = splat2(m[14]) * zero + rz;
+    return normalize3p(make3p(rx, ry, rz), g);
+}
+
+// color_blend(c, 0, t) for one pixel of a pair, channels from a packed texel (shade_blend)
+TR_HD void shade_blend_p(uint32_t ta, uint32_t tb, f2 t, uint32_t &ca, uint32_t &cb)
+{
+    const f2 k = (splat2(1.0f) - t) * splat2(0.0f);
+    ca = 0u;
+    cb = 0u;
+    for (int ch = 0; ch < 3; ch++) {
+        const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+        ca |= f32_to_u8(v.x) << (8 * ch);
+        cb |= f32_to_u8(v.y) << (8 * ch);
+    }
+}
+
+// Which closures have a two-pixel form
+#ifndef TR_PAIR_CLOSURES
+#define TR_PAIR_CLOSURES ((1 << FS_NORMAL_MAP) | (1 << FS_SPECULAR) | (1 << FS_DARBOUX))
+#endif
+constexpr bool has_pair_closure(int fs)
+{
+    return (fs == FS_NORMAL_MAP || fs == FS_SPECULAR || fs == FS_DARBOUX) && ((TR_PAIR_CLOSURES >> fs) & 1);
+}
+
+// The part of fragment closure `FS` after `uv = vertex_uvs * bar` for two pixels (possibly of
+// different polygons): `vary(k)` returns varying k of both.  bad_a / bad_b: that pixel left the
+// guarded range -- its colour must come from fragment_color<FS> instead (error bits too: the fast
+// path reports texture range errors only, the plain closure also a singular basis).
+template <int FS, typename VARY>
+TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, const VARY &vary, vec3p bar, f2 uu,
+                               f2 vv, uint32_t &ca, uint32_t &cb, uint32_t &ea, uint32_t &eb, bool &bad_a, bool &bad_b)
+{
+    const vec3p tl = splat3p(make3(u.t_light[0], u.t_light[1], u.t_light[2]));
+    PairGuard g = guard_init();
+    const uint32_t ta = fetch_texel(tex, 0, 0, uu.x, vv.x, ea), tb = fetch_texel(tex, 0, 0, uu.y, vv.y, eb);
+    f2 result;  // the value whose NaN-ness decides (every fast operation feeds it)
+    if (FS == FS_NORMAL_MAP) {
+        const vec3p tn = transform_normal_p(
+            u.it_m, decode_normal_p(fetch_texel(tex, 1, 1, uu.x, vv.x, ea), fetch_texel(tex, 1, 1, uu.y, vv.y, eb)), g);
+        result = dot3p(tl, tn);
+        shade_blend_p(ta, tb, result, ca, cb);
+    } else if (FS == FS_SPECULAR) {
+        const vec3p tn = transform_normal_p(
+            u.it_m, decode_normal_p(fetch_texel(tex, 1, 1, uu.x, vv.x, ea), fetch_texel(tex, 1, 1, uu.y, vv.y, eb)), g);
+        // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
+        const f2 d0 = dot3p(tl, tn);
+        const f2 two = splat2(2.0f);
+        const vec3p refl = normalize3p(make3p(two * (tn.x * d0) - tl.x, two * (tn.y * d0) - tl.y, two * (tn.z * d0) - tl.z), g);
+        const f2 diff = dot3p(tl, tn);
+        const float e0 = (float)(fetch_texel(tex, 3, 3, uu.x, vv.x, ea) & 0xFFu);
+        const float e1 = (float)(fetch_texel(tex, 3, 3, uu.y, vv.y, eb) & 0xFFu);
+        const f2 spec = splat2(0.6f) * mk2(tr_powf(fmaxf(refl.z.x, 0.0f), e0), tr_powf(fmaxf(refl.z.y, 0.0f), e1));
+        result = diff + spec;
+        ca = 0u;
+        cb = 0u;
+        for (int ch = 0; ch < 3; ch++) {
+            const f2 v = result * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu));
+            ca |= f32_to_u8(fminf(v.x, 255.0f)) << (8 * ch);
+            cb |= f32_to_u8(fminf(v.y, 255.0f)) << (8 * ch);
+        }
+    } else {  // FS_DARBOUX
+        const vec3p nt = decode_normal_p(fetch_texel(tex, 2, 1, uu.x, vv.x, ea), fetch_texel(tex, 2, 1, uu.y, vv.y, eb));
+        const vec3p local_z = mul_m3_v3p(make3p(vary(12), vary(13), vary(14)), make3p(vary(15), vary(16), vary(17)),
+                                         make3p(vary(18), vary(19), vary(20)), bar);
+        const vec3p r2 = normalize3p(local_z, g);
+        // 3x3 try_inverse of the matrix with rows r0, r1, r2 (nalgebra's cofactor form), nine quotients
+        // by one determinant
+        const f2 m11 = vary(6), m12 = vary(7), m13 = vary(8);
+        const f2 m21 = vary(9), m22 = vary(10), m23 = vary(11);
+        const f2 m31 = r2.x, m32 = r2.y, m33 = r2.z;
+        const f2 minor_m12_m23 = m22 * m33 - m32 * m23;
+        const f2 minor_m11_m23 = m21 * m33 - m31 * m23;
+        const f2 minor_m11_m22 = m21 * m32 - m31 * m22;
+        const f2 det = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+        const f2 c10 = -minor_m11_m23;
+        const f2 c01 = m13 * m32 - m33 * m12, c11 = m11 * m33 - m31 * m13, c21 = m12 * m31 - m32 * m11;
+        const f2 c02 = m12 * m23 - m22 * m13, c12 = m13 * m21 - m23 * m11, c22 = m11 * m22 - m21 * m12;
+        guard_add(g, det);
+        guard_add3(g, minor_m12_m23, c10, minor_m11_m22);
+        guard_add3(g, c01, c11, c21);
+        guard_add3(g, c02, c12, c22);
+        const f2 yd = rcp2(det);
+        const vec3p i0 = make3p(div_by2_nonzero(minor_m12_m23, det, yd), div_by2_nonzero(c10, det, yd),
+                                div_by2_nonzero(minor_m11_m22, det, yd));
+        const vec3p i1 = make3p(div_by2_nonzero(c01, det, yd), div_by2_nonzero(c11, det, yd), div_by2_nonzero(c21, det, yd));
+        const vec3p i2 = make3p(div_by2_nonzero(c02, det, yd), div_by2_nonzero(c12, det, yd), div_by2_nonzero(c22, det, yd));
+        const f2 u0 = vary(0), v0 = vary(1), zero = splat2(0.0f);
+        const vec3p local_x = mul_m3_v3p(i0, i1, i2, make3p(vary(2) - u0, vary(4) - u0, zero));
+        const vec3p local_y = mul_m3_v3p(i0, i1, i2, make3p(vary(3) - v0, vary(5) - v0, zero));
+        // normalize(local_z) is r2 again (the reference recomputes it, shader.rs:644-648)
+        const vec3p n = normalize3p(mul_m3_v3p(normalize3p(local_x, g), normalize3p(local_y, g), r2, nt), g);
+        result = dot3p(tl, n);
+        shade_blend_p(ta, tb, result, ca, cb);
+    }
+    bad_a = guard_bad(g, 0) || !(result.x == result.x);
+    bad_b = guard_bad(g, 1) || !(result.y == result.y);
 }
 
 }  // namespace tr

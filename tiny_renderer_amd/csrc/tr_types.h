@@ -88,9 +88,13 @@ struct alignas(16) Piece {
 };
 constexpr int REC_PIECES_SMALL = 6;  //  96 B
 constexpr int REC_PIECES_LARGE = 9;  // 144 B
-// Records a tile keeps resident in LDS (8 KiB worth = 85 / 56 records); larger bins take the
-// chunked path.  With the 16 KiB of keys a workgroup stays under 25 KiB: six fit in a CU's LDS.
-constexpr int LDS_REC_BYTES = 8192;
+// Records a tile keeps resident in LDS; larger bins take the chunked path, whose survivors' records
+// come from global memory when they are shaded.  Four waves per tile: 8 KiB (85 / 56 records) --
+// with the 16 KiB of keys a workgroup stays under 25 KiB and six fit in a CU's LDS.  The layouts
+// with more waves per tile are for frames whose tiles cannot fill the GPU; a CU holds three (8
+// waves) or two (16 waves) of their workgroups by wave count alone, so LDS is plentiful and the
+// heaviest tiles -- the critical path of a small frame -- stay resident (256 / 426 records).
+constexpr int lds_rec_bytes(int tile_waves) { return tile_waves == 4 ? 8192 : tile_waves == 8 ? 24576 : 40960; }
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {
