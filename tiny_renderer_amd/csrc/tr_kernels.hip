@@ -388,10 +388,15 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         a.tile_count_next[a.frame.ntx * a.frame.nty + tid] = 0u;  // k_order's bucket sizes and cursors
     if (n == 0u) {
         if (a.fresh) {
-            // an empty tile of a cleared frame: its colour is zeros; its z stays unwritten behind
-            // the tile's fast-clear flag (depth passes write their f32::MIN)
-            write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
-                                      (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
+            // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
+            // already holds them (it was empty the last time it was written, too: most of a frame,
+            // most of the time); its z stays unwritten behind the tile's fast-clear flag (depth passes
+            // write their f32::MIN)
+            if (DEPTH || a.fbclean == nullptr || a.fbclean[tile] == 0u) {
+                write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
+                                          (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
+                if (!DEPTH && tid == 0u && a.fbclean) a.fbclean[tile] = 1u;
+            }
             if (tid == 0u && a.zclean) a.zclean[tile] = 1u;
         }
         return;
@@ -803,6 +808,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         shade_steps(std::false_type{});
 
     if (a.zclean && tid == 0u) a.zclean[tile] = 0u;
+    if (!DEPTH && a.fbclean && tid == 0u) a.fbclean[tile] = 0u;
 
     if (a.stamps) {
         __syncthreads();

@@ -171,6 +171,18 @@ struct tr_scene {
     // memory not written".  Raised by the tile kernel for the empty tiles of a cleared frame (and by
     // a clear that has to be materialised), lowered by whoever writes the tile's z.
     uint32_t *d_zclean = nullptr;
+    // Colour counterpart, one flag set per frame buffer the scene has rendered into (its own, and the
+    // ones a caller alternates through tr_scene_set_frame_buffer_device): non-zero = the tile's colour
+    // and winner words in THAT buffer hold the cleared value, so an empty tile of a cleared frame is
+    // not stored again.  The buffer belongs to the scene while it is the target: whoever else writes
+    // its rows must call tr_scene_set_frame_buffer_device again (which forgets the flags of a buffer
+    // it has not seen, and keeps those of one it has).
+    struct FbFlags {
+        uint8_t *fb;
+        uint32_t *clean;
+    };
+    std::vector<FbFlags> fb_flags;
+    uint32_t *d_fbclean = nullptr;  // the current target's set
     uint64_t *d_stamps = nullptr;
     uint32_t *d_err = nullptr;
 
@@ -213,6 +225,33 @@ void dev_free(T *&p)
 {
     if (p) (void)hipFree(p);
     p = nullptr;
+}
+
+// Points d_fbclean at the flag set of the current frame buffer (allocated zeroed = "content unknown"
+// the first time a buffer is seen; at most a handful of buffers are remembered).
+int select_fb_flags(tr_scene *s)
+{
+    for (const tr_scene::FbFlags &f : s->fb_flags)
+        if (f.fb == s->d_fb) {
+            // the winner tap is one buffer shared by all targets: its tiles were last written with
+            // another target's frame, so a remembered "clean" says nothing about them
+            if (s->d_winner && s->d_fbclean != f.clean)
+                HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
+            s->d_fbclean = f.clean;
+            return TR_OK;
+        }
+    if (s->fb_flags.size() >= 8) {  // forget the oldest
+        (void)hipStreamSynchronize(s->stream);
+        dev_free(s->fb_flags.front().clean);
+        s->fb_flags.erase(s->fb_flags.begin());
+    }
+    tr_scene::FbFlags f = { s->d_fb, nullptr };
+    int st = dev_alloc(&f.clean, (size_t)s->n_tiles);
+    if (st != TR_OK) return st;
+    HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
+    s->fb_flags.push_back(f);
+    s->d_fbclean = f.clean;
+    return TR_OK;
 }
 
 hipEvent_t take_event(tr_scene *s)
@@ -321,6 +360,7 @@ int flush_clear_color(tr_scene *s)
     // z: raise every tile's fast-clear flag; colour (and the winner tap) are real memory
     HIP_TRY(hipMemsetAsync(s->d_zclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_fb + fb_first, 0, n * 3, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_fbclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
     if (s->d_winner) HIP_TRY(hipMemsetAsync(s->d_winner + z_first, 0xFF, n * 4, s->stream));
     s->z_fb_cleared = false;
     return TR_OK;
@@ -557,6 +597,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.fb = s->d_fb;
     ta.winner = s->d_winner;
     ta.zclean = depth_pass ? nullptr : s->d_zclean;
+    ta.fbclean = depth_pass ? nullptr : s->d_fbclean;
     ta.err = s->d_err;
     ta.fresh = fresh;
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
@@ -650,6 +691,7 @@ void destroy(tr_scene *s)
     dev_free(s->d_view);
     dev_free(s->d_winner);
     dev_free(s->d_zclean);
+    for (tr_scene::FbFlags &f : s->fb_flags) dev_free(f.clean);
     dev_free(s->d_stamps);
     dev_free(s->d_err);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -795,6 +837,9 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         if ((st = dev_alloc(&s->d_winner, npx))) return st;
         HIP_TRY(hipMemset(s->d_winner, 0xFF, npx * 4));
     }
+    if ((st = select_fb_flags(s))) return st;
+    if (s->d_fb == s->d_fb_own)  // zero-filled just now, winner tap at "no fragment": every tile is clean
+        HIP_TRY(hipMemsetAsync(s->d_fbclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
     if (o.flags & TR_OPT_TILE_STAMPS) {
         if ((st = dev_alloc(&s->d_stamps, (size_t)s->n_tiles_full * 8))) return st;
         HIP_TRY(hipMemset(s->d_stamps, 0, (size_t)s->n_tiles_full * 64));
@@ -1013,7 +1058,7 @@ int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device)
     HIP_TRY(hipSetDevice(s->device));
     if (frame_buffer_device) {
         s->d_fb = (uint8_t *)frame_buffer_device;
-        return TR_OK;
+        return select_fb_flags(s);
     }
     if (!s->d_fb_own) {
         const size_t n = (size_t)s->width * s->height * 3;
@@ -1022,7 +1067,7 @@ int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device)
         HIP_TRY(hipMemsetAsync(s->d_fb_own, 0, n, s->stream));
     }
     s->d_fb = s->d_fb_own;
-    return TR_OK;
+    return select_fb_flags(s);
 }
 
 int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1)

@@ -204,6 +204,10 @@ struct TileArgs {
     // Fast depth clear: zclean[t] != 0 says every z of colour-pass tile t is logically f32::MIN and
     // its memory is stale (null for depth passes, whose shadow buffer is looked up at random).
     uint32_t *zclean;
+    // Colour counterpart: fbclean[t] != 0 says every colour byte (and winner word) of tile t already holds
+    // the cleared value in memory -- the tile was empty when it was last written -- so an empty tile of
+    // a cleared frame has nothing to store.  Null for depth passes.
+    uint32_t *fbclean;
 };
 
 }  // namespace tr
