@@ -192,9 +192,9 @@ def main():
     #        be ordered behind it) into one of two frame tensors; the exchange of frame f runs on a
     #        second stream, ordered by events, under the render of frame f + 1.
     n_buf = 1 if (not use_dist or args.no_overlap) else 2
-    fbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
     render_stream = comm_stream = None
     band = None
+    exchange = None
     if use_dist:
         render_stream = torch.cuda.Stream()
         comm_stream = render_stream if args.no_overlap else torch.cuda.Stream()
@@ -203,17 +203,30 @@ def main():
         band = T.band_rows(H, world, rank)
         if len({T.band_rows(H, world, r)[1] - T.band_rows(H, world, r)[0] for r in range(world)}) != 1:
             raise SystemExit("frame height must divide by the number of GPUs (in-place all-gather)")
+    if use_dist and args.exchange == "peer":
+        # the library's exchange owns the frame slots (they are exported to the other ranks through HIP IPC)
+        exchange = T.PeerExchange(n_buf, H * W * 3, rank, world, device_index)
+        fbs = None
+        fb_ptr = [exchange.frame_ptr(b) for b in range(n_buf)]
+    else:
+        fbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+        fb_ptr = [fb.data_ptr() for fb in fbs]
     torch.cuda.synchronize()
     scene = T.Scene(W, H, mesh, texs, pipe, device=device_index,
                     stream=render_stream.cuda_stream if use_dist else None,
-                    frame_buffer_device=fbs[0].data_ptr(), band_rows=band)
+                    frame_buffer_device=fb_ptr[0], band_rows=band)
     chunks = None
-    exchange = None
+    band_bytes = 0
     if use_dist:
-        n = (band[1] - band[0]) * W * 3
-        chunks = [fb[rank * n:(rank + 1) * n] for fb in fbs]
-        if args.exchange == "peer":
-            exchange = T.PeerExchange(fbs, band, W, H, rank, world, dist)
+        band_bytes = (band[1] - band[0]) * W * 3
+        if fbs is not None:
+            chunks = [fb[rank * band_bytes:(rank + 1) * band_bytes] for fb in fbs]
+
+    def read_frame(b):
+        if exchange is not None:
+            return exchange.read(b, H, W)
+        return fbs[b].cpu().numpy().reshape(H, W, 3)
+
     rendered = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
     gathered = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
     gather_started = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
@@ -244,7 +257,7 @@ def main():
             if frame_no[0] > n_buf:
                 render_stream.wait_event(gathered[b])  # the exchange of the frame that used this buffer is done
             render_started[b].record(render_stream)
-            scene.set_frame_buffer_device(fbs[b].data_ptr())
+            scene.set_frame_buffer_device(fb_ptr[b])
             scene.clear()
             scene.set_light_direction(lt)
             scene.set_camera(*cam_now)
@@ -254,7 +267,7 @@ def main():
             comm_stream.wait_event(rendered[b])
             gather_started[b].record(comm_stream)
             if exchange is not None:
-                exchange.all_gather(b, comm_stream)
+                exchange.all_gather(b, rank * band_bytes, band_bytes, comm_stream.cuda_stream)
             else:
                 dist.all_gather_into_tensor(fbs[b], chunks[b])
             gathered[b].record(comm_stream)
@@ -268,9 +281,28 @@ def main():
         scene.flush()             # the scene may hold renders back to batch them: hand them over,
         torch.cuda.synchronize()  # then wait for every stream of the device
 
-    for _ in range(args.warmup):
-        step()
-    device_idle()
+    from tiny_renderer_amd.sharded import any_rank
+
+    def clean_sync():
+        """scene.sync() on every rank; True when no rank's triangle bins overflowed (the library has
+        grown them by then).  Taken together: a rank that repeated a loop on its own would issue more
+        collectives than its peers."""
+        overflow = False
+        try:
+            st = scene.sync()
+        except T.TinyRendererError as e:
+            if e.code != -9:
+                raise
+            overflow, st = True, e.code
+        return (not any_rank(overflow)), st
+
+    for attempt in range(4):   # warm-up; again if it is what made the bins grow
+        for _ in range(args.warmup):
+            step()
+        device_idle()
+        ok, _ = clean_sync()
+        if ok:
+            break
     barrier()
     device_idle()
     t0 = time.perf_counter()
@@ -280,7 +312,9 @@ def main():
     barrier()
     device_idle()
     elapsed = time.perf_counter() - t0
-    status = scene.sync()
+    ok, status = clean_sync()
+    if not ok:
+        raise SystemExit("triangle bins overflowed inside the timed region: the timing is void")
     last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -292,16 +326,13 @@ def main():
     # (deterministic stand-in for the reference's keyboard orbit, app.rs:173-200); not `value`.
     orbit_frames, orbit_elapsed, orbit_status = 200, None, None
     if extras:
-        for lap in range(3):   # warm-up laps: the bins grow to what every angle needs (a frame whose bins
-            try:               # overflowed on a caller's stream is reported, not silently repaired)
-                for i in range(orbit_frames):
-                    step(camera(2.0 * np.pi * i / orbit_frames))
-                device_idle()
-                scene.sync()
+        for lap in range(4):   # warm-up laps: the bins grow to what every angle needs (a frame whose bins
+            for i in range(orbit_frames):   # overflowed on a caller's stream is reported, not silently repaired)
+                step(camera(2.0 * np.pi * i / orbit_frames))
+            device_idle()
+            ok, _ = clean_sync()
+            if ok:
                 break
-            except T.TinyRendererError as e:
-                if e.code != -9:
-                    raise
         barrier()
         t1 = time.perf_counter()
         for i in range(orbit_frames):
@@ -309,10 +340,7 @@ def main():
         device_idle()
         barrier()
         orbit_elapsed = time.perf_counter() - t1
-        try:
-            orbit_status = scene.sync()
-        except T.TinyRendererError as e:
-            orbit_status = e.code
+        ok, orbit_status = clean_sync()
 
     # ---- single-frame latency: clear -> render -> sync with nothing else in flight -----------------
     latency_us = None
@@ -390,7 +418,7 @@ def main():
         stats = cpu.stats()
         color = stats[1] if pipe in ("shadow", "occlusion") else stats[0]
         n_shaded = color["frag_accept"]
-        gpu_frame = fbs[last_buf].cpu().numpy().reshape(H, W, 3)
+        gpu_frame = read_frame(last_buf)
         ref_frame = cpu.get_frame_buffer()
         diff = np.abs(gpu_frame.astype(np.int16) - ref_frame.astype(np.int16))
         # specular calls powf: exact when the library reproduces the host libm's (tr_specular_exact), else 1 LSB

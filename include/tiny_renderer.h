@@ -40,7 +40,8 @@ enum {
     TR_E_IO = -7,               /* file missing / unreadable (app.rs:94,99: `?`) */
     TR_E_FORMAT = -8,           /* unsupported OBJ / TGA content */
     TR_E_BIN_OVERFLOW = -9,     /* triangle-bin capacity exceeded; raise tr_options.bin_capacity */
-    TR_E_NOMEM = -10
+    TR_E_NOMEM = -10,
+    TR_E_EXCHANGE = -11         /* multi-GPU frame exchange: a peer's band did not arrive */
 };
 
 /* obj::raw::RawObj as the path reads it (util.rs:25-31, shader.rs:136-147,363-367,
@@ -140,6 +141,27 @@ int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device);
  * frame; they are equal (what an in-place all-gather needs) exactly when n divides height. */
 int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1);
 
+/* Multi-GPU frame exchange without RCCL (SURVEY.md 8e's hand-tuned alternative; nothing of the kind
+ * upstream).  One process per GPU.  Each rank creates its end -- one or two full-size frame buffers
+ * ("slots": pass their device pointers to tr_scene_create / tr_scene_set_frame_buffer_device) -- and
+ * publishes a TR_EXCHANGE_HANDLE_BYTES record; once every rank has connected to all records (in rank
+ * order; the host's own rendezvous carries them), tr_exchange_all_gather(slot, offset, bytes, stream)
+ * pushes bytes [offset, offset + bytes) of the local slot into the same range of every peer's slot
+ * with concurrent DMA-engine copies over xGMI, after the work queued on `stream` so far, and makes
+ * `stream` wait until every peer's range has arrived in the local slot.  Collective: every rank calls it
+ * for the same slots in the same order.  Failures of a peer surface as TR_E_EXCHANGE from
+ * tr_exchange_status / tr_exchange_read after a ten-second device-side timeout, never as a hang. */
+#define TR_EXCHANGE_HANDLE_BYTES 256
+typedef struct tr_exchange tr_exchange;
+int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, tr_exchange **out);
+void *tr_exchange_frame(tr_exchange *x, uint32_t slot);
+int tr_exchange_export(tr_exchange *x, void *record /* TR_EXCHANGE_HANDLE_BYTES */);
+int tr_exchange_connect(tr_exchange *x, const void *records /* n_ranks * TR_EXCHANGE_HANDLE_BYTES */);
+int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, void *hip_stream);
+int tr_exchange_status(tr_exchange *x);
+int tr_exchange_read(tr_exchange *x, uint32_t slot, void *host, size_t bytes); /* waits for the device, copies a slot out */
+void tr_exchange_destroy(tr_exchange *x);
+
 /* Diagnostic (TR_OPT_TILE_STAMPS): for each tile of the last colour pass {start, end} in 100 MHz
  * ticks, polygons in its bin, hardware id, {bin staged, coverage done} ticks, 2 spare.  `out`
  * holds 8 * n_tiles entries; returns n_tiles. */
@@ -205,6 +227,8 @@ void tr_free_image(tr_image_rgb8 *img);
 /* Frame writer (no counterpart upstream: the reference shows frames in a window): uncompressed
  * 24-bit TGA, top-left origin, i.e. exactly what tr_scene_get_frame_buffer returns. */
 int tr_save_tga_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h);
+/* The same frame as an 8-bit RGB PNG (stored deflate blocks: no compression library needed). */
+int tr_save_png_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h);
 
 const char *tr_last_error(void);
 int tr_abi_version(void);

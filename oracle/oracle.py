@@ -61,13 +61,23 @@ def build(force=False):
 
 
 _lib = None
+_variant_path = None
+
+
+def use_library(path=None):
+    """scripts/oracle_variants.py only: bind the module to another build of tr_oracle.c (a TRO_VARIANT).
+    Scenes created before the switch must not be used after it.  None = back to the normative oracle."""
+    global _lib, _variant_path
+    _lib = None
+    _variant_path = path
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        if _variant_path is None:
+            build()
+        L = C.CDLL(_variant_path or _LIB_PATH)
         L.tro_scene_new.restype = C.c_void_p
         L.tro_scene_new.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Mesh), C.POINTER(Image), C.c_char_p]
         L.tro_scene_free.argtypes = [C.c_void_p]

@@ -15,6 +15,21 @@
  */
 #include "tr_oracle.h"
 
+/* TRO_VARIANT (default 0 = the normative restatement).  Non-zero values build ALTERNATIVE readings
+ * of the nalgebra operations whose order SURVEY.md Appendix A could not verify against the crate's
+ * source; scripts/oracle_variants.py renders the BASELINE configs with each and counts the pixels
+ * that change, which is the size of the risk "parity unpinned" leaves:
+ *   1  dot of 3-vectors associates to the right: a0*b0 + (a1*b1 + a2*b2)
+ *   2  4x4 gemv sums pairwise: (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
+ *   3  gemv accumulates into a zeroed vector: y = 0 + col0*v0 + ... (differs in signed zeros only)
+ *   4  normalize multiplies by the reciprocal norm: v * (1 / n)
+ *   5  3x3 try_inverse multiplies the cofactors by 1 / det
+ *   6  4x4 try_inverse divides the cofactors by det
+ * Never used by tests/, smoke() or bench.py. */
+#ifndef TRO_VARIANT
+#define TRO_VARIANT 0
+#endif
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,7 +71,11 @@ static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z -
 static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
 /* a.dot(b) = (a0*b0 + a1*b1) + a2*b2 */
+#if TRO_VARIANT == 1
+static inline float v3_dot(v3 a, v3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+#else
 static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#endif
 /* a.cross(b) */
 static inline v3 v3_cross(v3 a, v3 b)
 {
@@ -66,7 +85,12 @@ static inline v3 v3_cross(v3 a, v3 b)
 static inline v3 v3_normalize(v3 a)
 {
     float n = sqrtf(v3_dot(a, a));
+#if TRO_VARIANT == 4
+    float r = 1.0f / n;
+    return v3_make(a.x * r, a.y * r, a.z * r);
+#else
     return v3_make(a.x / n, a.y / n, a.z / n);
+#endif
 }
 
 /* 4x4, column-major: element (r,c) = m[c*4 + r].  M*v is nalgebra's column-accumulating
@@ -74,9 +98,17 @@ static inline v3 v3_normalize(v3 a)
 void tro_mat4_mul_vec4(const float a[16], const float v[4], float out[4])
 {
     float y[4];
+#if TRO_VARIANT == 2
+    for (int i = 0; i < 4; i++) y[i] = (a[i] * v[0] + a[4 + i] * v[1]) + (a[8 + i] * v[2] + a[12 + i] * v[3]);
+#elif TRO_VARIANT == 3
+    for (int i = 0; i < 4; i++) y[i] = 0.0f;
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) y[i] = a[j * 4 + i] * v[j] + y[i];
+#else
     for (int i = 0; i < 4; i++) y[i] = a[0 * 4 + i] * v[0];
     for (int j = 1; j < 4; j++)
         for (int i = 0; i < 4; i++) y[i] = a[j * 4 + i] * v[j] + y[i];
+#endif
     for (int i = 0; i < 4; i++) out[i] = y[i];
 }
 
@@ -143,15 +175,23 @@ int tro_mat4_inverse(const float m[16], float out[16])
     inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10]
             + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
 
+#if TRO_VARIANT == 6
+    for (int i = 0; i < 16; i++) out[i] = inv[i] / det;
+#else
     float inv_det = 1.0f / det;
     for (int i = 0; i < 16; i++) out[i] = inv[i] * inv_det;
+#endif
     return 1;
 }
 
 /* 3x3, column-major: element (r,c) = a[c*3 + r]. */
 static inline v3 mat3_mul_v3(const float a[9], v3 v)
 {
+#if TRO_VARIANT == 3
+    float y0 = a[0] * v.x + 0.0f, y1 = a[1] * v.x + 0.0f, y2 = a[2] * v.x + 0.0f;
+#else
     float y0 = a[0] * v.x, y1 = a[1] * v.x, y2 = a[2] * v.x;
+#endif
     y0 = a[3] * v.y + y0; y1 = a[4] * v.y + y1; y2 = a[5] * v.y + y2;
     y0 = a[6] * v.z + y0; y1 = a[7] * v.z + y1; y2 = a[8] * v.z + y2;
     return v3_make(y0, y1, y2);
@@ -181,6 +221,20 @@ int tro_mat3_inverse(const float a[9], float out[9])
     r[2] = minor_m11_m22 / det;                /* (2,0) */
     r[5] = (m12 * m31 - m32 * m11) / det;      /* (2,1) */
     r[8] = (m11 * m22 - m21 * m12) / det;      /* (2,2) */
+#if TRO_VARIANT == 5
+    {
+        const float rd = 1.0f / det;
+        r[0] = minor_m12_m23 * rd;
+        r[3] = (m13 * m32 - m33 * m12) * rd;
+        r[6] = (m12 * m23 - m22 * m13) * rd;
+        r[1] = -minor_m11_m23 * rd;
+        r[4] = (m11 * m33 - m31 * m13) * rd;
+        r[7] = (m13 * m21 - m23 * m11) * rd;
+        r[2] = minor_m11_m22 * rd;
+        r[5] = (m12 * m31 - m32 * m11) * rd;
+        r[8] = (m11 * m22 - m21 * m12) * rd;
+    }
+#endif
     memcpy(out, r, sizeof r);
     return 1;
 }

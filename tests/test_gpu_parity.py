@@ -617,3 +617,76 @@ def test_pair_rcp_sqrt_exhaustive(built):
         T._lib.check(L.tr_selftest_device_unary(0, which, lo, hi, C.byref(nt), C.byref(nb), bits))
         assert nt.value == (hi - lo + 1) << 23
         assert nb.value == 0, [hex(b) for b in bits if b]
+
+
+def _oracle_frame(W, Hh, mesh, texs, pipe, ca, la):
+    from oracle import oracle as O
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    cpu.clear()
+    cpu.set_light_direction(H.light(la))
+    cpu.set_camera(*H.camera(ca))
+    assert cpu.render() == 0
+    return cpu.get_frame_buffer()
+
+
+@pytest.mark.parametrize("pipe,ext", [("phong", "png"), ("shadow", "tga"), ("darboux", "ppm")])
+def test_cli_writes_the_oracles_frame(synthetic, tmp_path, pipe, ext):
+    """The headless CLI (main.rs:9-39's -p / -s plus explicit size and angles): the file it writes is the
+    oracle's frame, through all three writers."""
+    from PIL import Image
+    import tiny_renderer_amd as T
+    from tiny_renderer_amd import cli
+    mesh, texs = synthetic
+    out = str(tmp_path / ("frame." + ext))
+    rc = cli.main(["--synthetic", "-s", pipe, "--width", "640", "--height", "360", "--camera-angle", "0.4",
+                   "--light-angle", "-0.3", "--out", out])
+    assert rc == 0
+    got = T.load_tga(out) if ext == "tga" else np.array(Image.open(out).convert("RGB"))
+    assert np.array_equal(got, _oracle_frame(640, 360, mesh, texs, pipe, 0.4, -0.3))
+
+
+def test_cli_sharded_single_rank(synthetic, tmp_path):
+    """`--gpus` code path of the CLI (ShardedScene: band scene on a torch side stream, two frame tensors,
+    RCCL all-gather on a second stream) with a one-rank process group, in its own process; several
+    frames with a moving camera, the last one must be the oracle's."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    mesh, texs = synthetic
+    out = str(tmp_path / "sharded.png")
+    env = dict(os.environ, TR_CLI_FORCE_DIST="1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "tiny_renderer_amd.cli", "--synthetic", "-s", "shadow", "--width", "512",
+                        "--height", "384", "--frames", "5", "--light-angle", "0.5", "--gpus", "1", "--out", out],
+                       env=env, cwd=H.REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.array(Image.open(out).convert("RGB"))
+    angle = float(np.float32(2.0 * np.pi * 4 / 5))
+    assert np.array_equal(got, _oracle_frame(512, 384, mesh, texs, "shadow", angle, 0.5))
+
+
+def test_peer_exchange_two_processes_one_gpu(diablo):
+    """The library's own frame exchange (tr_exchange_*: HIP IPC mapped frame slots, concurrent DMA-engine
+    band copies, generation flags) with TWO rank processes sharing this box's one GPU: bench.py's N = 2
+    code path end to end -- band scenes, two frame slots, exchange on a second stream, a moving-camera
+    leg -- and its closing comparison of the assembled frame with the oracle (rank 0 exits non-zero on a
+    mismatch, e.g. a band that arrived late or stale).  Cross-GPU coherence cannot show on one device;
+    that run is the driver's."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--exchange", "peer", "--size", "1024",
+                        "--steps", "40", "--warmup", "5", "--no-cpu"], env=env, cwd=H.REPO, capture_output=True,
+                       text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["group_ranks"] == 2 and j["parity_vs_oracle"]["ok"]
+    assert "peer-to-peer" in j["config"]["sharding"] and len(j["per_rank"]) == 2
+    assert j["per_rank"][0]["band_rows"] == [0, 512] and j["per_rank"][1]["band_rows"] == [512, 1024]

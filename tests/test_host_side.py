@@ -214,3 +214,17 @@ def test_specular_exact_is_checked_on_this_host(built):
     """tr_specular_exact() compares the shipped powf with the running C library's at first use."""
     import tiny_renderer_amd as T
     assert T.load_library().tr_specular_exact() == 1  # this image and the GPU box: glibc 2.35, same tables
+
+
+def test_png_writer_roundtrip(built, tmp_path):
+    """tr_save_png_rgb8 (stored deflate blocks, own CRC-32 / Adler-32) read back by an independent decoder."""
+    from PIL import Image
+    import tiny_renderer_amd as T
+    rng = np.random.default_rng(4)
+    for shape in ((1, 1), (37, 53), (300, 21846)):   # the last: rows longer than one 65535-byte stored block
+        img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+        path = str(tmp_path / "t.png")
+        T.save_png(path, img)
+        assert np.array_equal(np.array(Image.open(path).convert("RGB")), img)
+    with pytest.raises(T.TinyRendererError):
+        T.save_png(str(tmp_path / "no" / "dir.png"), img)

@@ -8,9 +8,10 @@ without the built library or without a GPU raises.
 """
 from ._lib import build_library, library_path, load_library, TinyRendererError  # noqa: F401
 from .scene import Scene, PIPELINES, prepare_uniforms, band_rows  # noqa: F401
-from .assets import load_assets, load_obj, load_tga, save_tga  # noqa: F401
+from .assets import load_assets, load_obj, load_tga, save_tga, save_png  # noqa: F401
 from .synthetic import synthetic_scene, instanced_grid  # noqa: F401
+from .sharded import ShardedScene, PeerExchange, launch_ranks  # noqa: F401
 
-__all__ = ["Scene", "PIPELINES", "prepare_uniforms", "band_rows", "load_assets", "load_obj", "load_tga", "save_tga",
+__all__ = ["Scene", "PIPELINES", "prepare_uniforms", "band_rows", "load_assets", "load_obj", "load_tga", "save_tga", "save_png",
            "synthetic_scene", "instanced_grid", "build_library", "library_path", "load_library",
            "TinyRendererError"]

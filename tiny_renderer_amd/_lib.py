@@ -18,6 +18,8 @@ TR_E_IO = -7
 TR_E_FORMAT = -8
 TR_E_BIN_OVERFLOW = -9
 TR_E_NOMEM = -10
+TR_E_EXCHANGE = -11
+TR_EXCHANGE_HANDLE_BYTES = 256
 
 TR_OPT_WINNER_TAP = 0x1
 TR_OPT_TILE_STAMPS = 0x2
@@ -88,6 +90,14 @@ SYMBOLS = {
     "tr_scene_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int]),
     "tr_scene_profile_frame_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tr_selftest_device_math": (C.c_int, [C.c_int, _FP, _FP, C.c_uint32] + [C.c_void_p] * 5),
+    "tr_exchange_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tr_exchange_frame": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "tr_exchange_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tr_exchange_all_gather": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "tr_exchange_status": (C.c_int, [C.c_void_p]),
+    "tr_exchange_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "tr_exchange_destroy": (None, [C.c_void_p]),
     "tr_selftest_device_unary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "tr_pipeline_count": (C.c_int, []),
@@ -99,6 +109,7 @@ SYMBOLS = {
     "tr_load_tga_rgb8": (C.c_int, [C.c_char_p, C.POINTER(ImageRgb8)]),
     "tr_free_image": (None, [C.POINTER(ImageRgb8)]),
     "tr_save_tga_rgb8": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "tr_save_png_rgb8": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "tr_last_error": (C.c_char_p, []),
     "tr_abi_version": (C.c_int, []),
     "tr_specular_exact": (C.c_int, []),

@@ -45,6 +45,12 @@ def save_tga(path, rgb):
     check(load_library().tr_save_tga_rgb8(os.fsencode(path), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
 
 
+def save_png(path, rgb):
+    """Write an [H, W, 3] uint8 frame (row 0 = top) as an 8-bit RGB PNG."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    check(load_library().tr_save_png_rgb8(os.fsencode(path), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
+
+
 def load_assets(asset_path):
     """-p <asset dir>: returns (mesh, [texture, normal_map, normal_map_tangent, specular_map])."""
     mesh = load_obj(os.path.join(asset_path, ASSET_FILES[0]))

@@ -1,9 +1,12 @@
 """Headless counterpart of the reference's CLI (src/main.rs:9-39: `-p <asset dir>`, `-s <pipeline>`).
 
 The reference opens a window and orbits with the keyboard; here the camera / light angles are
-explicit and frames are written as binary PPM.  Rendering happens on the GPU through the C ABI.
+explicit and the last frame is written as PNG, TGA or binary PPM.  Rendering happens on the GPU
+through the C ABI.  `--gpus N` shards every frame by screen rows over N GPUs of the node (one
+process per GPU, started from here; RCCL all-gather of the frame buffer, sharded.py).
 """
 import argparse
+import os
 import sys
 import time
 
@@ -24,23 +27,68 @@ def main(argv=None):
                          "camera turns at CAMERA_SPEED = 3 rad/s as if a key were held, `FPS --- n` every second")
     ap.add_argument("--no-readback", action="store_true",
                     help="with --seconds: leave the frames on the GPU (the reference hands every frame to its window)")
-    ap.add_argument("--out", default=None, help="write the last frame: .tga (24-bit) or binary PPM otherwise")
+    ap.add_argument("--out", default=None, help="write the last frame: .png, .tga (24-bit) or binary PPM otherwise")
     ap.add_argument("--view", choices=("frame", "z", "shadow"), default="frame")  # app.rs:213-215
     ap.add_argument("--device", type=int, default=-1)
     ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of -p")
+    ap.add_argument("--gpus", type=int, default=1, help="shard every frame by screen rows over this many GPUs")
     args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # --gpus N > 1 outside a launcher: start the N ranks from here, before anything touches a GPU
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        from .sharded import launch_ranks
+        return launch_ranks(args.gpus, os.path.abspath(__file__), list(argv) if argv is not None else sys.argv[1:])
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    sharded = world > 1 or os.environ.get("TR_CLI_FORCE_DIST") == "1"
+    rank = int(os.environ.get("RANK", "0"))
+    say = print if rank == 0 else (lambda *a, **k: None)
 
     import tiny_renderer_amd as T
 
     if args.synthetic:
         mesh, texs = T.synthetic_scene()
     else:
-        print("loading model from: %s/model.obj" % args.asset_path)
+        say("loading model from: %s/model.obj" % args.asset_path)
         mesh, texs = T.load_assets(args.asset_path)
-    print("number of vertices in a model: %d" % mesh["pos"].shape[0])
-    print("number of polygons in a model: %d" % mesh["idx"].shape[0])
-    print("cooking up a scene with '%s' shader pipeline" % args.pipeline)
-    scene = T.Scene(args.width, args.height, mesh, texs, args.pipeline, device=args.device)
+    say("number of vertices in a model: %d" % mesh["pos"].shape[0])
+    say("number of polygons in a model: %d" % mesh["idx"].shape[0])
+    say("cooking up a scene with '%s' shader pipeline" % args.pipeline)
+    if sharded:
+        import torch
+        import torch.distributed as dist
+        from .sharded import ShardedScene
+        if args.seconds > 0:
+            # every rank must render the same frames: wall-clock driven angles would differ per process
+            raise SystemExit("--seconds (the time-based loop) runs on one GPU: use --frames with --gpus")
+        if args.view != "frame":
+            raise SystemExit("--view %s needs the whole z / shadow buffer on one GPU: use --gpus 1" % args.view)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+        scene = ShardedScene(args.width, args.height, mesh, texs, args.pipeline, device=local)
+    else:
+        scene = T.Scene(args.width, args.height, mesh, texs, args.pipeline, device=args.device)
+    rc = _run(args, T, scene, sharded, rank, say)
+    if sharded:
+        import torch.distributed as dist
+        scene.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+def _run(args, T, scene, sharded, rank, say):
 
     if args.seconds > 0:
         # app.rs:12-13,160-165,173-199,230-246: angles advance by speed * frame time; a frame counter is
@@ -65,12 +113,13 @@ def main(argv=None):
                 scene.sync()  # keep the queue bounded
             fps_counter += 1
             if now - fps_t > 1.0:
-                print("FPS --- %d" % fps_counter)
+                say("FPS --- %d" % fps_counter)
                 fps_counter, fps_t = 0, now
         scene.sync()
         if args.out:
-            img = {"frame": scene.get_frame_buffer, "z": scene.get_z_buffer, "shadow": scene.get_shadow_buffer}[args.view]()
-            write_frame(T, args.out, img)
+            img = _view(scene, args.view)
+            if rank == 0:
+                write_frame(T, args.out, img)
         return 0
 
     t0 = time.perf_counter()
@@ -81,17 +130,25 @@ def main(argv=None):
         scene.set_light_direction([float(np.sin(la)), 0.0, float(np.cos(la))])   # app.rs:203-208
         scene.set_camera([float(np.sin(ca)), 0.0, float(np.cos(ca))], [0, 0, 0], [0, 1, 0])  # app.rs:200-209
         scene.render()                                                       # app.rs:210
-    img = {"frame": scene.get_frame_buffer, "z": scene.get_z_buffer, "shadow": scene.get_shadow_buffer}[args.view]()
+    img = _view(scene, args.view)
     dt = time.perf_counter() - t0
-    print("FPS --- %d" % int(args.frames / dt if dt > 0 else 0))              # app.rs:238
-    if args.out:
+    say("FPS --- %d" % int(args.frames / dt if dt > 0 else 0))              # app.rs:238
+    if args.out and rank == 0:
         write_frame(T, args.out, img)
     return 0
+
+
+def _view(scene, view):
+    if view == "frame":
+        return scene.get_frame_buffer()
+    return {"z": scene.get_z_buffer, "shadow": scene.get_shadow_buffer}[view]()
 
 
 def write_frame(T, path, img):
     if path.lower().endswith(".tga"):
         T.save_tga(path, img)
+    elif path.lower().endswith(".png"):
+        T.save_png(path, img)
     else:
         with open(path, "wb") as fh:
             fh.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))

@@ -1,0 +1,256 @@
+// tr_exchange.cpp -- the hand-tuned alternative to the RCCL all-gather of the frame buffer
+// ("7 concurrent peer copies ... measure both").
+//
+// One process per GPU.  Every rank owns one or two full-size frame buffers ("slots") in device
+// memory and exports them (hipIpcGetMemHandle); after the handles have been exchanged -- by
+// whatever rendezvous the host has: torch.distributed in bench.py -- every rank holds all its
+// peers' slots mapped.  An all-gather of slot b is then, on rank r:
+//
+//   1. tell every peer "my slot b is open for generation g" (a 4-byte store into the peer's flag block)
+//   2. per peer p, on a stream of its own: wait for p's "open", copy r's band into p's slot b with the
+//      DMA engines (hipMemcpyAsync device-to-device over xGMI: no compute unit is involved, so the
+//      copies run beside the next frame's tile kernel, which an RCCL kernel cannot: a machine-filling
+//      kernel starves another queue's workgroups, profiles/r02_notes.md), then store "arrived, g"
+//   3. on the caller's stream: join the copy streams, wait until every peer's "arrived" says g
+//
+// Flags are generation counters in uncached device memory (hipDeviceMallocUncached), written across
+// GPUs by one-lane kernels with system-scope stores and awaited by one-lane-per-flag kernels that spin
+// with s_sleep and give up after ten seconds (TR_E_EXCHANGE instead of a hung GPU).  All n - 1 band
+// copies leave at once: xGMI is point to point, each of the 7 links carries one band.
+//
+// Not in the reference (single process, single thread); replaces nothing of it.  Selected with
+// `bench.py --exchange peer`; covered on one GPU by two processes sharing the device
+// (tests/test_gpu_parity.py::test_peer_exchange_two_processes_one_gpu) -- cross-GPU runs are the
+// driver's (8-GPU node).
+#include <hip/hip_runtime_api.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "tiny_renderer.h"
+#include "tr_error.h"
+#include "tr_kernels.h"
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return tr::fail(TR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+constexpr uint32_t MAX_SLOTS = 2;
+constexpr uint32_t MAX_RANKS = 64;
+
+// what a rank publishes
+struct Blob {
+    uint32_t magic, rank, n_ranks, n_slots;
+    uint64_t frame_bytes;
+    hipIpcMemHandle_t frame[MAX_SLOTS];
+    hipIpcMemHandle_t flags;
+};
+static_assert(sizeof(Blob) <= TR_EXCHANGE_HANDLE_BYTES, "blob must fit the published size");
+
+// flag block of one rank (uncached): [kind][slot][peer] generation counters, plus an error word
+struct FlagIndex {
+    static uint32_t open(uint32_t slot, uint32_t peer) { return (0 * MAX_SLOTS + slot) * MAX_RANKS + peer; }
+    static uint32_t arrived(uint32_t slot, uint32_t peer) { return (1 * MAX_SLOTS + slot) * MAX_RANKS + peer; }
+    static uint32_t error() { return 2 * MAX_SLOTS * MAX_RANKS; }
+    static uint32_t words() { return 2 * MAX_SLOTS * MAX_RANKS + 16; }
+};
+}  // namespace
+
+struct tr_exchange {
+    int device = 0;
+    uint32_t n_ranks = 0, rank = 0, n_slots = 0;
+    size_t frame_bytes = 0;
+    uint8_t *frame[MAX_SLOTS] = {};
+    uint32_t *flags = nullptr;              // this rank's block (peers write into it)
+    std::vector<uint8_t *> peer_frame[MAX_SLOTS];  // [slot][rank], own entry = own pointer
+    std::vector<uint32_t *> peer_flags;            // [rank]
+    std::vector<hipStream_t> copy_stream;          // [rank]
+    std::vector<hipEvent_t> copy_done;             // [rank]
+    hipEvent_t fork = nullptr;
+    uint32_t generation[MAX_SLOTS] = {};
+    uint32_t **d_wait_list = nullptr;  // device array of flag pointers for the arrival wait: [slot][peer]
+    uint32_t **d_open_list = nullptr;  // ... and of the peers' "open" flags this rank stores into: [slot][peer]
+    bool connected = false;
+};
+
+extern "C" {
+
+int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, tr_exchange **out)
+{
+    if (!out) return tr::fail(TR_E_INVALID, "null out pointer");
+    *out = nullptr;
+    if (n_ranks == 0 || n_ranks > MAX_RANKS || rank >= n_ranks || n_slots == 0 || n_slots > MAX_SLOTS || frame_bytes == 0)
+        return tr::fail(TR_E_INVALID, "tr_exchange_create: need rank < n_ranks <= 64, 1..2 slots, a non-empty frame");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDevice(&device));
+    tr_exchange *x = new tr_exchange();
+    x->device = device;
+    x->n_ranks = n_ranks;
+    x->rank = rank;
+    x->n_slots = n_slots;
+    x->frame_bytes = frame_bytes;
+    hipError_t e = hipSuccess;
+    for (uint32_t b = 0; b < n_slots && e == hipSuccess; b++) {
+        e = hipMalloc((void **)&x->frame[b], frame_bytes);
+        if (e == hipSuccess) e = hipMemset(x->frame[b], 0, frame_bytes);
+    }
+    if (e == hipSuccess) e = hipExtMallocWithFlags((void **)&x->flags, FlagIndex::words() * 4, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(x->flags, 0, FlagIndex::words() * 4);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        tr_exchange_destroy(x);
+        return tr::fail(TR_E_HIP, std::string("tr_exchange_create: ") + hipGetErrorString(e));
+    }
+    *out = x;
+    return TR_OK;
+}
+
+void *tr_exchange_frame(tr_exchange *x, uint32_t slot) { return (x && slot < x->n_slots) ? x->frame[slot] : nullptr; }
+
+int tr_exchange_export(tr_exchange *x, void *blob)
+{
+    if (!x || !blob) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(x->device));
+    Blob b;
+    memset(&b, 0, sizeof b);
+    b.magic = 0x54524558u;  // "TREX"
+    b.rank = x->rank;
+    b.n_ranks = x->n_ranks;
+    b.n_slots = x->n_slots;
+    b.frame_bytes = x->frame_bytes;
+    for (uint32_t s = 0; s < x->n_slots; s++) HIP_TRY(hipIpcGetMemHandle(&b.frame[s], x->frame[s]));
+    HIP_TRY(hipIpcGetMemHandle(&b.flags, x->flags));
+    memset(blob, 0, TR_EXCHANGE_HANDLE_BYTES);
+    memcpy(blob, &b, sizeof b);
+    return TR_OK;
+}
+
+int tr_exchange_connect(tr_exchange *x, const void *blobs)
+{
+    if (!x || !blobs) return tr::fail(TR_E_INVALID, "null argument");
+    if (x->connected) return tr::fail(TR_E_INVALID, "tr_exchange_connect: already connected");
+    HIP_TRY(hipSetDevice(x->device));
+    for (uint32_t s = 0; s < x->n_slots; s++) x->peer_frame[s].assign(x->n_ranks, nullptr);
+    x->peer_flags.assign(x->n_ranks, nullptr);
+    x->copy_stream.assign(x->n_ranks, nullptr);
+    x->copy_done.assign(x->n_ranks, nullptr);
+    for (uint32_t p = 0; p < x->n_ranks; p++) {
+        Blob b;
+        memcpy(&b, (const uint8_t *)blobs + (size_t)p * TR_EXCHANGE_HANDLE_BYTES, sizeof b);
+        if (b.magic != 0x54524558u || b.rank != p || b.n_ranks != x->n_ranks || b.n_slots != x->n_slots ||
+            b.frame_bytes != x->frame_bytes)
+            return tr::fail(TR_E_INVALID, "tr_exchange_connect: the peers' records do not describe the same exchange");
+        if (p == x->rank) {
+            for (uint32_t s = 0; s < x->n_slots; s++) x->peer_frame[s][p] = x->frame[s];
+            x->peer_flags[p] = x->flags;
+            continue;
+        }
+        for (uint32_t s = 0; s < x->n_slots; s++)
+            HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_frame[s][p], b.frame[s], hipIpcMemLazyEnablePeerAccess));
+        HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_flags[p], b.flags, hipIpcMemLazyEnablePeerAccess));
+        HIP_TRY(hipStreamCreateWithFlags(&x->copy_stream[p], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&x->copy_done[p], hipEventDisableTiming));
+    }
+    // the arrival wait's list of flag addresses, per slot: [slot][peer] -> &own flags[arrived(slot, peer)]
+    std::vector<uint32_t *> list((size_t)MAX_SLOTS * x->n_ranks, nullptr);
+    for (uint32_t s = 0; s < x->n_slots; s++)
+        for (uint32_t p = 0; p < x->n_ranks; p++) list[(size_t)s * x->n_ranks + p] = x->flags + FlagIndex::arrived(s, p);
+    HIP_TRY(hipMalloc((void **)&x->d_wait_list, list.size() * sizeof(uint32_t *)));
+    HIP_TRY(hipMemcpy(x->d_wait_list, list.data(), list.size() * sizeof(uint32_t *), hipMemcpyHostToDevice));
+    for (uint32_t s = 0; s < x->n_slots; s++)
+        for (uint32_t p = 0; p < x->n_ranks; p++)
+            list[(size_t)s * x->n_ranks + p] = x->peer_flags[p] + FlagIndex::open(s, x->rank);
+    HIP_TRY(hipMalloc((void **)&x->d_open_list, list.size() * sizeof(uint32_t *)));
+    HIP_TRY(hipMemcpy(x->d_open_list, list.data(), list.size() * sizeof(uint32_t *), hipMemcpyHostToDevice));
+    x->connected = true;
+    return TR_OK;
+}
+
+int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, void *stream_)
+{
+    if (!x || !x->connected) return tr::fail(TR_E_INVALID, "tr_exchange_all_gather: not connected");
+    if (slot >= x->n_slots || offset > x->frame_bytes || bytes > x->frame_bytes - offset)
+        return tr::fail(TR_E_INVALID, "tr_exchange_all_gather: slot or byte range outside the frame");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(x->device));
+    const uint32_t g = ++x->generation[slot];
+    const uint32_t r = x->rank;
+    // 1. my slot is open for generation g -- ordered after everything the caller queued on `stream`
+    //    (its consumer of the slot's previous content, and the render of this band)
+    if (x->n_ranks > 1) {
+        int rc = tr::launch_flags_store_all(x->d_open_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g, stream);
+        if (rc) return tr::fail(TR_E_HIP, "flag store launch failed");
+    }
+    HIP_TRY(hipEventRecord(x->fork, stream));
+    // 2. per peer: wait for its "open", copy my band with the DMA engines, say "arrived"
+    for (uint32_t p = 0; p < x->n_ranks; p++) {
+        if (p == r) continue;
+        hipStream_t c = x->copy_stream[p];
+        HIP_TRY(hipStreamWaitEvent(c, x->fork, 0));
+        int rc = tr::launch_flag_wait(x->flags + FlagIndex::open(slot, p), g, x->flags + FlagIndex::error(), c);
+        if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
+        if (bytes)
+            HIP_TRY(hipMemcpyAsync(x->peer_frame[slot][p] + offset, x->frame[slot] + offset, bytes, hipMemcpyDeviceToDevice, c));
+        rc = tr::launch_flag_store(x->peer_flags[p] + FlagIndex::arrived(slot, r), g, c);
+        if (rc) return tr::fail(TR_E_HIP, "flag store launch failed");
+        HIP_TRY(hipEventRecord(x->copy_done[p], c));
+    }
+    // 3. the caller's stream continues when my copies have left and every peer's band has arrived
+    for (uint32_t p = 0; p < x->n_ranks; p++)
+        if (p != r) HIP_TRY(hipStreamWaitEvent(stream, x->copy_done[p], 0));
+    if (x->n_ranks > 1) {
+        int rc = tr::launch_flags_wait_all(x->d_wait_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g,
+                                           x->flags + FlagIndex::error(), stream);
+        if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
+    }
+    return TR_OK;
+}
+
+int tr_exchange_status(tr_exchange *x)
+{
+    if (!x) return tr::fail(TR_E_INVALID, "null exchange");
+    HIP_TRY(hipSetDevice(x->device));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, x->flags + FlagIndex::error(), 4, hipMemcpyDeviceToHost));
+    if (err) return tr::fail(TR_E_EXCHANGE, "a peer's band did not arrive within ten seconds (the rank is gone or out of step)");
+    return TR_OK;
+}
+
+int tr_exchange_read(tr_exchange *x, uint32_t slot, void *host, size_t bytes)
+{
+    if (!x || !host || slot >= x->n_slots || bytes > x->frame_bytes) return tr::fail(TR_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(x->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, x->frame[slot], bytes, hipMemcpyDeviceToHost));
+    return tr_exchange_status(x);
+}
+
+void tr_exchange_destroy(tr_exchange *x)
+{
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    (void)hipDeviceSynchronize();
+    for (uint32_t p = 0; p < x->peer_flags.size(); p++) {
+        if (p == x->rank) continue;
+        for (uint32_t s = 0; s < x->n_slots; s++)
+            if (x->peer_frame[s].size() > p && x->peer_frame[s][p]) (void)hipIpcCloseMemHandle(x->peer_frame[s][p]);
+        if (x->peer_flags[p]) (void)hipIpcCloseMemHandle(x->peer_flags[p]);
+        if (x->copy_stream[p]) (void)hipStreamDestroy(x->copy_stream[p]);
+        if (x->copy_done[p]) (void)hipEventDestroy(x->copy_done[p]);
+    }
+    if (x->fork) (void)hipEventDestroy(x->fork);
+    if (x->d_wait_list) (void)hipFree(x->d_wait_list);
+    if (x->d_open_list) (void)hipFree(x->d_open_list);
+    for (uint32_t s = 0; s < MAX_SLOTS; s++)
+        if (x->frame[s]) (void)hipFree(x->frame[s]);
+    if (x->flags) (void)hipFree(x->flags);
+    delete x;
+}
+
+}  // extern "C"

@@ -904,7 +904,84 @@ __global__ __launch_bounds__(256) void k_selftest_unary(int which, uint32_t firs
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// Peer exchange flags (tr_exchange.cpp): generation counters in uncached memory, possibly another
+// GPU's.  Stores and loads are system scope; a waiter sleeps between polls and gives up after about
+// ten seconds of the 100 MHz wall clock, raising the error word instead of hanging the queue.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_flag_store(uint32_t *flag, uint32_t value)
+{
+    if (threadIdx.x == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// one launch tells every peer: lane p stores into peer p's block
+__global__ __launch_bounds__(64) void k_flags_store_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value)
+{
+    if (threadIdx.x < n && threadIdx.x != skip) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(flags[threadIdx.x], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__device__ __forceinline__ void spin_until_at_least(uint32_t *flag, uint32_t value, uint32_t *error)
+{
+    const uint64_t t0 = wall_clock64();
+    // generations are compared as a signed distance so that the counter may wrap
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 1000000000ull) {  // 10 s
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+__global__ __launch_bounds__(64) void k_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error)
+{
+    if (threadIdx.x == 0u) spin_until_at_least(flag, value, error);
+}
+
+__global__ __launch_bounds__(64) void k_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value,
+                                                       uint32_t *error)
+{
+    if (threadIdx.x < n && threadIdx.x != skip) spin_until_at_least(flags[threadIdx.x], value, error);
+}
+
 }  // namespace
+
+int launch_flag_store(uint32_t *flag, uint32_t value, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_flag_store, dim3(1), dim3(64), 0, st, flag, value);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int launch_flags_store_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, hipStream_t st)
+{
+    if (n > 64u) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_flags_store_all, dim3(1), dim3(64), 0, st, flags, n, skip, value);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int launch_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, st, flag, value, error);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, uint32_t *error, hipStream_t st)
+{
+    if (n > 64u) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_flags_wait_all, dim3(1), dim3(64), 0, st, flags, n, skip, value, error);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
 
 int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned long long *n_bad, uint32_t *bad_bits,
                           hipStream_t st)

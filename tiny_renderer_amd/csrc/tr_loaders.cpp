@@ -276,6 +276,89 @@ extern "C" int tr_save_tga_rgb8(const char *path, const uint8_t *rgb, uint32_t w
     return TR_OK;
 }
 
+// PNG frame writer: 8-bit RGB, filter 0, the image data in stored (uncompressed) deflate blocks --
+// a valid PNG any viewer opens, written without a compression library.
+namespace {
+uint32_t crc32_update(uint32_t c, const uint8_t *p, size_t n)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t k = i;
+            for (int j = 0; j < 8; j++) k = (k & 1u) ? 0xEDB88320u ^ (k >> 1) : k >> 1;
+            table[i] = k;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    return c;
+}
+void put_be32(std::vector<uint8_t> &v, uint32_t x)
+{
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+bool write_chunk(FILE *f, const char type[4], const std::vector<uint8_t> &data)
+{
+    std::vector<uint8_t> head;
+    put_be32(head, (uint32_t)data.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t c = crc32_update(0xFFFFFFFFu, head.data() + 4, 4);
+    if (!data.empty()) c = crc32_update(c, data.data(), data.size());
+    std::vector<uint8_t> tail;
+    put_be32(tail, c ^ 0xFFFFFFFFu);
+    return fwrite(head.data(), 1, head.size(), f) == head.size() &&
+           (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+           fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+}
+}  // namespace
+
+extern "C" int tr_save_png_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h)
+{
+    if (!path || (!rgb && w && h)) return tr::fail(TR_E_INVALID, "tr_save_png_rgb8: null argument");
+    if (w == 0 || h == 0 || w > 65535u || h > 65535u) return tr::fail(TR_E_INVALID, "tr_save_png_rgb8: sides must be within 1..65535");
+    FILE *f = fopen(path, "wb");
+    if (!f) return tr::fail(TR_E_IO, std::string("cannot write ") + path);
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    bool ok = fwrite(sig, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w);
+    put_be32(ihdr, h);
+    const uint8_t fmt[5] = { 8, 2, 0, 0, 0 };  // bit depth 8, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+    ihdr.insert(ihdr.end(), fmt, fmt + 5);
+    ok = ok && write_chunk(f, "IHDR", ihdr);
+    // zlib stream: header, stored blocks of at most 65535 bytes over the filtered scanlines, adler32
+    const size_t stride = (size_t)w * 3 + 1, total = stride * h;
+    std::vector<uint8_t> z;
+    z.reserve(total + total / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    std::vector<uint8_t> raw(total);
+    for (uint32_t y = 0; y < h; y++) {
+        raw[y * stride] = 0;  // filter type 0
+        memcpy(&raw[y * stride + 1], rgb + (size_t)y * w * 3, (size_t)w * 3);
+    }
+    for (size_t off = 0; off < total; off += 65535) {
+        const size_t n = total - off < 65535 ? total - off : 65535;
+        z.push_back(off + n == total ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+    }
+    for (size_t i = 0; i < total;) {  // adler32 in runs short enough not to overflow 32 bits
+        const size_t n = total - i < 5552 ? total - i : 5552;
+        for (size_t k = 0; k < n; k++) { a += raw[i + k]; b += a; }
+        a %= 65521u; b %= 65521u;
+        i += n;
+    }
+    put_be32(z, (b << 16) | a);
+    ok = ok && write_chunk(f, "IDAT", z) && write_chunk(f, "IEND", std::vector<uint8_t>());
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return tr::fail(TR_E_IO, std::string("short write to ") + path);
+    return TR_OK;
+}
+
 extern "C" void tr_free_image(tr_image_rgb8 *img)
 {
     if (img && img->rgb) {

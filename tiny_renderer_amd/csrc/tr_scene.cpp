@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -626,7 +627,8 @@ int run_pass(tr_scene *s, const PassDesc &p)
     // on the library's own stream up to BATCH passes wait for company -- but only while the main
     // stream still has tile kernels to run: holding work back from an idle queue (the first frames
     // after a sync) would leave the GPU waiting for the host to issue three more frames
-    if ((int)s->pending.size() >= BATCH) return submit_pending(s);
+    static const int batch = getenv("TR_BATCH") ? atoi(getenv("TR_BATCH")) : BATCH;  // experiment hook (1..BATCH)
+    if ((int)s->pending.size() >= (batch < 1 ? 1 : batch > BATCH ? BATCH : batch)) return submit_pending(s);
     if (s->tiles_submitted == 0 || hipEventQuery(s->ev_tile[(s->last_submitted_seq) % RING]) == hipSuccess)
         return submit_pending(s);
     return TR_OK;

@@ -1,0 +1,206 @@
+"""Screen-band sharding of one frame over the GPUs of a node (north_star).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL).  Rank r renders output rows
+tr_band_rows(height, world, r) -- the reference's own clamp rectangle (scene.rs:236-239) cut to
+the band, so a band is bit-identical to the same rows of the single-GPU frame -- into its slice
+of a full-size frame tensor, and the bands are exchanged with one in-place all-gather per frame.
+Frames are double-buffered: the exchange of frame f runs on a second stream, ordered by events,
+under the render of frame f + 1.  Depth passes of shadow / occlusion are rendered for the whole
+frame on every rank (their lookups are in light space, shader.rs:774-778): no second collective.
+
+`ShardedScene` mirrors the reference's `Scene` methods (clear / set_light_direction / set_camera /
+render / get_frame_buffer) so that the headless CLI can drive either; bench.py spells the same
+loop out because it times its parts.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+from .scene import Scene, band_rows
+
+
+def launch_ranks(n_gpus, script, argv):
+    """Starts `n_gpus` rank processes of `script` (one per GPU) with torch.distributed.run and returns
+    their exit code.  Must be called from a process that has not touched a GPU (no torch.cuda call):
+    the ranks are children, nothing is exec'ed over an initialised process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    sys.stderr.write("starting %d ranks: %s\n" % (n_gpus, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def any_rank(flag, device=None):
+    """True on every rank if `flag` is true on any (one tiny all-reduce).  Decisions that change how many
+    collectives a rank issues -- rendering a frame again after its bins overflowed -- must be taken
+    together, or the ranks fall out of step and the next collective never completes."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+                     device=("cuda:%d" % (torch.cuda.current_device() if device is None else device)) if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
+class ShardedScene:
+    """Scene::new(...) for one rank of an initialised process group; every rank ends up with the whole frame."""
+
+    def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=None, **scene_kw):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.width, self.height = int(width), int(height)
+        self.band = band_rows(self.height, self.world, self.rank)
+        if len({band_rows(self.height, self.world, r)[1] - band_rows(self.height, self.world, r)[0]
+                for r in range(self.world)}) != 1:
+            raise ValueError("frame height %d must divide by the number of GPUs %d (in-place all-gather)"
+                             % (self.height, self.world))
+        if device is None:
+            device = torch.cuda.current_device()
+        self._render = torch.cuda.Stream(device=device)
+        self._comm = torch.cuda.Stream(device=device)
+        assert self._render.cuda_stream != 0  # tr_options.stream = NULL would mean a library-owned stream
+        n_all = self.width * self.height * 3
+        self._fbs = [torch.zeros(n_all, dtype=torch.uint8, device="cuda:%d" % device) for _ in range(2)]
+        n = (self.band[1] - self.band[0]) * self.width * 3
+        self._chunks = [fb[self.rank * n:(self.rank + 1) * n] for fb in self._fbs]
+        self._rendered = [torch.cuda.Event() for _ in range(2)]
+        self._gathered = [torch.cuda.Event() for _ in range(2)]
+        torch.cuda.synchronize(device)
+        self._scene = Scene(width, height, mesh, textures, shader_pipeline_name, device=device,
+                            stream=self._render.cuda_stream, frame_buffer_device=self._fbs[0].data_ptr(),
+                            band_rows=self.band, **scene_kw)
+        self._slot = 1          # the first frame goes to slot 0
+        self._cleared = True    # Scene::new leaves cleared (zero-filled) targets
+        self._used = [False, False]
+        self._last_was_cleared = True
+
+    # --- the reference's methods -------------------------------------------------------------
+    def clear(self):
+        self._cleared = True
+        self._scene.clear()
+
+    def set_light_direction(self, v):
+        self._scene.set_light_direction(v)
+
+    def set_camera(self, look_from, look_at, up):
+        self._scene.set_camera(look_from, look_at, up)
+
+    def render(self):
+        """Renders this rank's band and starts its exchange.  The reference's per-frame protocol is
+        clear -> set_* -> render: a cleared frame moves on to the other frame tensor (so that the
+        previous frame's exchange can still be running); a render WITHOUT a clear accumulates into the
+        same tensor, as `render` does upstream (scene.rs:151), and is exchanged again."""
+        torch, dist = self._torch, self._dist
+        if self._cleared:
+            self._slot ^= 1
+        b = self._slot
+        with torch.cuda.stream(self._render):
+            if self._used[b]:
+                self._render.wait_event(self._gathered[b])  # the slot's previous exchange has finished
+            self._scene.set_frame_buffer_device(self._fbs[b].data_ptr())
+            self._scene.render()  # a caller's stream holds the frame's kernels when render() returns
+            self._rendered[b].record(self._render)
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(self._rendered[b])
+            dist.all_gather_into_tensor(self._fbs[b], self._chunks[b])
+            self._gathered[b].record(self._comm)
+        self._used[b] = True
+        self._last_was_cleared = self._cleared
+        self._cleared = False
+
+    def sync(self):
+        """Waits for the frames issued so far on every rank (collective: all ranks call it together).
+        A band whose triangle bins overflowed was exchanged truncated -- the scene renders on a caller's
+        stream, where the library reports that instead of repairing it behind the consumer's back
+        (TR_E_BIN_OVERFLOW) -- so the last frame is rendered and exchanged again, by ALL ranks, now that
+        the bins have grown."""
+        from ._lib import TinyRendererError, TR_E_BIN_OVERFLOW
+        for attempt in range(4):
+            self._torch.cuda.synchronize()
+            overflow = False
+            try:
+                status = self._scene.sync()
+            except TinyRendererError as e:
+                if e.code != TR_E_BIN_OVERFLOW:
+                    raise
+                overflow, status = True, e.code
+            if not any_rank(overflow):
+                return status
+            if not self._last_was_cleared:
+                raise TinyRendererError(TR_E_BIN_OVERFLOW, "bins overflowed during an accumulating render: clear and render again")
+            self._scene.clear()          # same light and camera: the scene still holds them
+            self._cleared = True
+            self._slot ^= 1              # ... and the same frame tensor
+            self.render()
+        raise TinyRendererError(TR_E_BIN_OVERFLOW, "triangle bins kept overflowing")
+
+    def get_frame_buffer(self):
+        """The whole frame (all bands), [H, W, 3] uint8, row 0 = top.  Collective, like sync()."""
+        status = self.sync()
+        if status != 0:
+            raise RuntimeError("device status %d" % status)
+        return self._fbs[self._slot].cpu().numpy().reshape(self.height, self.width, 3)
+
+    def close(self):
+        self._torch.cuda.synchronize()
+        self._scene.close()
+
+
+
+
+class PeerExchange:
+    """The library's own frame exchange (tr_exchange_*, include/tiny_renderer.h): every rank's frame
+    slots mapped into every other rank through HIP IPC, bands pushed with concurrent DMA-engine copies.
+    `dist` (any initialised torch.distributed backend, gloo is enough) only carries the 256-byte
+    connection records."""
+
+    def __init__(self, n_slots, frame_bytes, rank, world, device):
+        import ctypes as C
+        import torch.distributed as dist
+        from ._lib import check, load_library, TR_EXCHANGE_HANDLE_BYTES
+        L = load_library()
+        self._L, self._check = L, check
+        self.n_slots, self.frame_bytes, self.rank, self.world = n_slots, frame_bytes, rank, world
+        h = C.c_void_p()
+        check(L.tr_exchange_create(device, world, rank, n_slots, frame_bytes, C.byref(h)))
+        self._h = h
+        mine = C.create_string_buffer(TR_EXCHANGE_HANDLE_BYTES)
+        check(L.tr_exchange_export(h, mine))
+        records = [None] * world
+        if world > 1:
+            dist.all_gather_object(records, bytes(mine.raw))
+        else:
+            records[0] = bytes(mine.raw)
+        check(L.tr_exchange_connect(h, b"".join(records)))
+        if world > 1:
+            dist.barrier()   # nobody pushes before everybody has mapped everybody
+
+    def frame_ptr(self, slot):
+        return self._L.tr_exchange_frame(self._h, slot)
+
+    def all_gather(self, slot, offset, nbytes, hip_stream):
+        self._check(self._L.tr_exchange_all_gather(self._h, slot, offset, nbytes, hip_stream))
+
+    def read(self, slot, height, width):
+        import numpy as np
+        out = np.empty((height, width, 3), np.uint8)
+        self._check(self._L.tr_exchange_read(self._h, slot, out.ctypes.data, out.nbytes))
+        return out
+
+    def status(self):
+        return self._check(self._L.tr_exchange_status(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.tr_exchange_destroy(self._h)
+            self._h = None
