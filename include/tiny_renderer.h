@@ -80,7 +80,10 @@ typedef struct tr_options {
     uint32_t tile_waves;       /* wavefronts per 128x16 screen tile: 4, 8, 16, or 0 = automatic (more
                                   while the tiles cannot fill the GPU, 4 from 4096x4096 up).
                                   Speed only: results do not depend on it. */
-    uint32_t reserved0;
+    uint32_t tile_mode;        /* how a tile's wavefronts divide its work: 1 = each owns a column of the tile and
+                                  sees every polygon of the bin, 2 = each owns a share of the bin and sees the
+                                  whole tile (depth resolve through LDS atomics), 0 = automatic.
+                                  Speed only: results do not depend on it. */
 } tr_options;
 
 typedef struct tr_scene tr_scene;

@@ -63,11 +63,13 @@ def test_synthetic_all_pipelines(synthetic, pipe):
 
 @pytest.mark.parametrize("pipe", ALL)
 @pytest.mark.parametrize("waves", [4, 8, 16])
-def test_tile_layouts(synthetic, pipe, waves):
-    """tr_options.tile_waves: four, eight or sixteen wavefronts per screen tile (the automatic choice
-    takes sixteen for frames this small, four from 4096^2 up); results must not depend on it."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_tile_layouts(synthetic, pipe, waves, mode):
+    """tr_options.tile_waves / tile_mode: four, eight or sixteen wavefronts per screen tile, each owning a
+    column of the tile (1) or a share of its bin with the depth resolve through LDS atomics (2); the
+    automatic choice goes by tile count.  Results must not depend on any of it."""
     mesh, texs = synthetic
-    gpu, cpu = render_pair(801, 603, mesh, texs, pipe, -0.3, 0.9, tile_waves=waves)
+    gpu, cpu = render_pair(801, 603, mesh, texs, pipe, -0.3, 0.9, tile_waves=waves, tile_mode=mode)
     assert_parity(gpu, cpu, pipe)
     for s in (gpu, cpu):  # and an accumulating render on top
         s.set_camera(*H.camera(0.8))
@@ -457,7 +459,7 @@ def test_random_api_sequences(small_synthetic, seed):
     # (occlusion is left out: a random light can hit the antiparallel case in which the reference panics)
     pipe = ["phong", "shadow", "default", "normal_map", "darboux", "specular"][seed % 6]
     W, Hh = [(320, 200), (1100, 700), (640, 64)][seed % 3]
-    gpu = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_waves=[0, 4, 8, 16][seed % 4])
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_waves=[0, 4, 8, 16][seed % 4], tile_mode=[0, 2, 1][seed % 3])
     cpu = O.Scene(W, Hh, mesh, texs, pipe)
     pinned = gpu.pinned_frame()
     pending_async = False

@@ -65,8 +65,14 @@ def test_resolve_matches_serial_order_cpu(seed, n_tri, grid, pipe, ca, size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("seed", range(12))
-def test_resolve_matches_serial_order_gpu(built, seed):
+def test_resolve_matches_serial_order_gpu(built, seed, mode):
+    """Polygon soups on a coarse vertex grid: many fragments of equal depth at the same pixel (shared
+    vertices and edges, coplanar overlaps), where the survivor is decided by polygon order alone --
+    in both depth-resolve forms of the tile kernel (1: private keys + index compare, 2: shared keys,
+    the order packed under the depth in one 64-bit atomic maximum), and, with accumulating renders,
+    against what the buffers held before."""
     import tiny_renderer_amd as T
     rng = np.random.default_rng(1000 + seed)
     n_tri = int(rng.integers(1, 400))
@@ -78,11 +84,14 @@ def test_resolve_matches_serial_order_gpu(built, seed):
     err, s = oracle_frame(W, Hh, mesh, texs, pipe, ca, 0.4)
     if err:
         pytest.skip("the reference would panic on this soup")
-    g = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True)
+    g = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_mode=mode, tile_waves=[0, 4, 8, 16][seed % 4])
     g.clear()
     g.set_light_direction(H.light(0.4))
     g.set_camera(*H.camera(ca))
     g.render()
+    if seed % 2:   # the same frame again WITHOUT a clear: every fragment now ties with the buffer's content
+        g.render()
+        assert s.render() == 0
     fb = g.get_frame_buffer()
     assert np.array_equal(g.read_winner_u32(), s.winner_u32())
     assert np.array_equal(g.read_z_f32().view(np.uint32), s.z_f32().view(np.uint32))
@@ -139,7 +148,7 @@ def test_far_vertices_and_slivers_gpu(built, seed):
     err, s = oracle_frame(W, Hh, mesh, texs, pipe, 0.0, 0.4)
     if err:
         pytest.skip("the reference would panic on this soup")
-    g = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_waves=waves)
+    g = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True, tile_waves=waves, tile_mode=1 + seed % 2)
     g.clear()
     g.set_light_direction(H.light(0.4))
     g.set_camera(*H.camera(0.0))

@@ -46,7 +46,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("band_row0", C.c_uint32), ("band_row1", C.c_uint32), ("stream", C.c_void_p),
                 ("frame_buffer_device", C.c_void_p), ("bin_capacity", C.c_uint64),
-                ("tile_waves", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("tile_waves", C.c_uint32), ("tile_mode", C.c_uint32)]
 
 
 class KernelTime(C.Structure):

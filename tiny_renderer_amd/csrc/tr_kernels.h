@@ -16,8 +16,11 @@ int launch_setup(int vs_kind, const SetupArgs &a, hipStream_t st, hipEvent_t sta
 // Builds the tile kernel's work list from the counters k_setup filled (same stream, after it).
 int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkItem *order, uint32_t n_tiles, hipStream_t st, hipEvent_t start,
                  hipEvent_t done);
-// tile_waves: 4 or 8 wavefronts per tile workgroup (see tr_types.h).
-int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, hipStream_t st, hipEvent_t start, hipEvent_t done);
+// tile_waves: 4, 8 or 16 wavefronts per tile workgroup (see tr_types.h); shared != 0: the waves share the
+// tile's bin and resolve through atomic keys instead of each owning a column of the tile (k_tile's
+// SHARED parameter; falls back to columns when n_polygons or a.bin_cap exceed the key's fields).
+int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, hipStream_t st,
+                hipEvent_t start, hipEvent_t done);
 int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,

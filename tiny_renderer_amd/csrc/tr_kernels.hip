@@ -351,12 +351,35 @@ constexpr int tile_waves_per_eu(int fs, int tile_waves)
     return want;
 }
 
-template <int FS, int TILE_WAVES>
+// Keys of the SHARED resolve (below): one 64-bit word per pixel, compared as an unsigned integer by
+// an LDS atomic maximum.  High half: the depth as an order-preserving integer (-0.0 folded onto +0.0:
+// the reference's `z <= zbuf` treats them as equal).  Low half: who wins among equal depths --
+//   a colour fragment: (2^20 - 1 - polygon id) << 12 | bin slot + 1   -> the lowest polygon index
+//   what the buffer held before the pass: all ones in a colour pass (`z <= zbuf` rejects: it beats
+//   every fragment of equal depth), zero in a depth pass (`z >= shadow` accepts: it loses)
+// Field limits: polygon ids below 2^20, bin slots below 4093 (launch_tile falls back to the column
+// mode beyond them).
+constexpr uint32_t SHARED_MAX_POLYGONS = 1u << 20, SHARED_MAX_SLOTS = 4093u;
+__device__ __forceinline__ uint32_t depth_order_bits(float z)
+{
+    uint32_t b = __float_as_uint(z);
+    b = b == 0x80000000u ? 0u : b;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// SHARED = false: every wave owns a column of the tile (32 / 16 / 8 pixels wide) and sees the whole
+// bin; its pixels' keys are private, plain LDS reads and writes.
+// SHARED = true: every wave sees the whole tile and owns an interleaved share of the BIN (record j
+// belongs to wave j mod waves); keys are shared and updated with 64-bit LDS atomic maxima.  Waves then
+// carry equal loads wherever the polygons cluster (the eyes of a head at 800^2: one 8-pixel column
+// held 80 of a tile's 120 polygons and its wave ran 20 us while the others idled), and a polygon is
+// visited once per tile instead of once per column it touches.
+template <int FS, int TILE_WAVES, bool SHARED>
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES), tile_waves_per_eu(FS, TILE_WAVES)))) void k_tile(TileArgs a)
 {
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
-    constexpr int QUAD = TILE_W / TILE_WAVES;  // width of a wave's column
+    constexpr int QUAD = SHARED ? TILE_W : TILE_W / TILE_WAVES;  // width of the region a wave resolves
     constexpr int NBX = QUAD / 8;              // 8x8 lane blocks per quadrant row
     constexpr int QPIX = QUAD * TILE_H;
     constexpr int WAVES_PER_STRIP = TILE_WAVES / (TILE_W / STRIP);  // shading: waves sharing a 32-pixel strip
@@ -366,9 +389,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     constexpr int NMAX = lds_rec_bytes(TILE_WAVES) / (P * 16);  // records resident in LDS
 
-    // Per pixel: .x = z of the best fragment so far (f32 bits; compared as floats, so -0.0 and
-    // +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what the
-    // buffer held before this pass").
+    // Per pixel, column mode: .x = z of the best fragment so far (f32 bits; compared as floats, so
+    // -0.0 and +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what
+    // the buffer held before this pass").  Shared mode: the 64-bit key described above (.y = depth
+    // order bits, .x = tie-break word whose low 12 bits are the bin slot + 1).
     __shared__ uint2 s_key[TILE_W * TILE_H];
     __shared__ uint4 s_rec[NMAX * P];
 
@@ -418,14 +442,26 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // is every z of this tile logically f32::MIN (cleared frame, or fast-clear flag still set)?
     // then nothing is read and every live z is written, after which the flag is down
     const bool zfresh = a.fresh || (a.zclean && a.zclean[tile] != 0u);
-    const int32_t qx0 = tile_x0 + (int32_t)wave * QUAD, qy0 = tile_y0;
-    uint2 *wkey = s_key + wave * QPIX;
+    const int32_t qx0 = SHARED ? tile_x0 : tile_x0 + (int32_t)wave * QUAD, qy0 = tile_y0;
+    uint2 *wkey = SHARED ? s_key : s_key + wave * QPIX;
+    constexpr uint32_t PREV_TAG = DEPTH ? 0u : 0xFFFFFFFFu;  // shared mode: tie-break word of the buffer's old content
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     const uint4 *bin = reinterpret_cast<const uint4 *>(a.bins) + (size_t)tile * a.bin_cap * P;
     const bool resident = n <= (uint32_t)NMAX;  // the whole bin stays in LDS through shading
 
     // ---- initial keys -------------------------------------------------------------------
-    {
+    if (SHARED) {
+        // the waves initialise the tile's blocks between them (block b of the block-major key array)
+        for (int b = (int)wave; b < NBX * NBY; b += TILE_WAVES) {
+            uint32_t zb = TR_F32_MIN_BITS;
+            if (!zfresh) {
+                const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
+                if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
+                    zb = __float_as_uint(depth[(size_t)py * W + px]);
+            }
+            wkey[(b << 6) + lane] = make_uint2(PREV_TAG, depth_order_bits(__uint_as_float(zb)));
+        }
+    } else {
 #pragma unroll
         for (int b = 0; b < NBX * NBY; b++) {
             uint32_t zb = TR_F32_MIN_BITS;
@@ -451,8 +487,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         __syncthreads();
         if (a.stamps && c0 == 0u) t_staged = wall_clock64();
 
-        for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
-            const uint32_t jj = j0 + lane;
+        // column mode: every wave takes all m records, 64 per round; shared mode: record jj belongs to
+        // wave jj mod TILE_WAVES, a round covers 64 * TILE_WAVES records
+        for (uint32_t j0 = 0; j0 < m; j0 += SHARED ? 64u * (uint32_t)TILE_WAVES : 64u) {
+            const uint32_t jj = SHARED ? j0 + lane * (uint32_t)TILE_WAVES + wave : j0 + lane;
             uint4 r0 = make_uint4(1u, 0u, 1u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
             uint32_t ry = 0u;
             if (jj < m) {
@@ -503,7 +541,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                     const bool rows = (int32_t)r0.z <= qy0 + 8 * j + 7 && (int32_t)r0.w >= qy0 + 8 * j;
                     const float n0 = __builtin_fmaf(8.0f * j, e0y, m0), n1 = __builtin_fmaf(8.0f * j, e1y, m1);
                     const float n2 = __builtin_fmaf(8.0f * j, e2y, m2);
-#pragma unroll
+#pragma unroll 4
                     for (int i = 0; i < NBX; i++) {
                         const bool cols = (int32_t)r0.x <= qx0 + 8 * i + 7 && (int32_t)r0.y >= qx0 + 8 * i;
                         const bool alive = rows && cols && __builtin_fmaf(8.0f * i, e0x, n0) >= 0.0f &&
@@ -524,7 +562,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                 const float z0 = __int_as_float(bcast(r2.z, l)), z1 = __int_as_float(bcast(r2.w, l));
                 const float z2 = __int_as_float(bcast(r3.x, l));
                 const uint32_t id = (uint32_t)bcast(r3.y, l);
-                const uint32_t slot1 = c0 + j0 + l + 1u;
+                const uint32_t slot1 = SHARED ? c0 + j0 + l * (uint32_t)TILE_WAVES + wave + 1u : c0 + j0 + l + 1u;
                 const uint32_t live_blocks = (uint32_t)bcast(lmask, l);
                 Edge2 e;
                 e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
@@ -561,7 +599,26 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                     const f2 rest = czp - (cx + cy);
                     const bool hita = inx && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
                     const bool hitb = inx && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
-                    if (hita || hitb) {
+                    if (SHARED) {
+                        if (hita || hitb) {
+                            // shared keys: the candidate (depth order bits, tie-break word) against what the
+                            // pixel holds now -- a plain read, possibly stale, but keys only grow, so a
+                            // candidate that does not beat it can never win -- then one atomic maximum
+                            const Bary2 bar = barycentric2_for_compare(cx, cy, e);
+                            const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
+                            const uint32_t tag = (((SHARED_MAX_POLYGONS - 1u) - id) << 12) | slot1;
+                            const unsigned long long ka = ((unsigned long long)depth_order_bits(z.x) << 32) | tag;
+                            const unsigned long long kb = ((unsigned long long)depth_order_bits(z.y) << 32) | tag;
+                            const unsigned long long ca_ = ((unsigned long long)cur_a.y << 32) | cur_a.x;
+                            const unsigned long long cb_ = ((unsigned long long)cur_b.y << 32) | cur_b.x;
+                            if (hita && ka > ca_)
+                                __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot_a), ka, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (hitb && kb > cb_)
+                                __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot_b), kb, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else if (hita || hitb) {
                         // depth of both fragments; only compared here (the survivor's stored z is
                         // recomputed with exact zero signs when it is shaded)
                         const Bary2 bar = barycentric2_for_compare(cx, cy, e);
@@ -610,7 +667,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // Addresses are a per-wave base (scalar registers) plus a 32-bit lane offset built with 24-bit
     // multiplies: 64-bit and 32 x 32 multiplies run at quarter rate and were a third of this
     // phase's vector-ALU time.
-    if (TILE_WAVES != TILE_W / STRIP) __syncthreads();  // a strip spans several waves' columns
+    if (SHARED || TILE_WAVES != TILE_W / STRIP) __syncthreads();  // a strip holds pixels other waves resolved
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
     const int32_t strip_x = (int32_t)(wave / (uint32_t)WAVES_PER_STRIP) * STRIP;  // within the tile
@@ -642,7 +699,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             row[u] = sstep * 4 + u * 2 + hrow;  // within the strip
             py[u] = sy0 + row[u];
             live[u] = col_live && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
-            const uint32_t s1 = s_key[key_slot<QUAD>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
+            uint32_t s1;
+            if (SHARED) {
+                // tie-break word: low 12 bits = bin slot + 1 of a fragment, 0xFFF / 0 = the buffer's old content
+                const uint32_t f = s_key[key_slot<QUAD>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].x & 0xFFFu;
+                s1 = (f == 0xFFFu) ? 0u : f;
+            } else {
+                s1 = s_key[key_slot<QUAD>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
+            }
             won[u] = live[u] && s1 != 0u;
             wslot[u] = won[u] ? s1 - 1u : 0u;
         }
@@ -1036,33 +1100,42 @@ int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, hipStr
     return 0;
 }
 
-template <int WAVES>
+template <int WAVES, bool SHARED>
 static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     const dim3 grid(n_tiles), block(64 * WAVES);
     switch (fs) {
-    case FS_DEFAULT: hipExtLaunchKernelGGL((k_tile<FS_DEFAULT, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_PHONG: hipExtLaunchKernelGGL((k_tile<FS_PHONG, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_NORMAL_MAP: hipExtLaunchKernelGGL((k_tile<FS_NORMAL_MAP, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_SPECULAR: hipExtLaunchKernelGGL((k_tile<FS_SPECULAR, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_DARBOUX: hipExtLaunchKernelGGL((k_tile<FS_DARBOUX, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_SHADOW2: hipExtLaunchKernelGGL((k_tile<FS_SHADOW2, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_OCCLUSION2: hipExtLaunchKernelGGL((k_tile<FS_OCCLUSION2, WAVES>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_DEPTH: hipExtLaunchKernelGGL((k_tile<FS_DEPTH, WAVES>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_DEFAULT: hipExtLaunchKernelGGL((k_tile<FS_DEFAULT, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_PHONG: hipExtLaunchKernelGGL((k_tile<FS_PHONG, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_NORMAL_MAP: hipExtLaunchKernelGGL((k_tile<FS_NORMAL_MAP, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_SPECULAR: hipExtLaunchKernelGGL((k_tile<FS_SPECULAR, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_DARBOUX: hipExtLaunchKernelGGL((k_tile<FS_DARBOUX, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_SHADOW2: hipExtLaunchKernelGGL((k_tile<FS_SHADOW2, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_OCCLUSION2: hipExtLaunchKernelGGL((k_tile<FS_OCCLUSION2, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    case FS_DEPTH: hipExtLaunchKernelGGL((k_tile<FS_DEPTH, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
     default: return (int)hipErrorInvalidValue;
     }
     TR_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_tile(int fs, const TileArgs &a, int tile_waves, hipStream_t st, hipEvent_t start, hipEvent_t done)
+int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, hipStream_t st, hipEvent_t start,
+                hipEvent_t done)
 {
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
-    if (tile_waves == 16) return launch_tile_waves<16>(fs, a, n_tiles, st, start, done);
-    if (tile_waves == 8) return launch_tile_waves<8>(fs, a, n_tiles, st, start, done);
-    if (tile_waves == 4) return launch_tile_waves<4>(fs, a, n_tiles, st, start, done);
+    // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns
+    if (n_polygons > SHARED_MAX_POLYGONS || a.bin_cap > SHARED_MAX_SLOTS) shared = 0;
+    if (shared) {
+        if (tile_waves == 16) return launch_tile_waves<16, true>(fs, a, n_tiles, st, start, done);
+        if (tile_waves == 8) return launch_tile_waves<8, true>(fs, a, n_tiles, st, start, done);
+        if (tile_waves == 4) return launch_tile_waves<4, true>(fs, a, n_tiles, st, start, done);
+    } else {
+        if (tile_waves == 16) return launch_tile_waves<16, false>(fs, a, n_tiles, st, start, done);
+        if (tile_waves == 8) return launch_tile_waves<8, false>(fs, a, n_tiles, st, start, done);
+        if (tile_waves == 4) return launch_tile_waves<4, false>(fs, a, n_tiles, st, start, done);
+    }
     return (int)hipErrorInvalidValue;
 }
 

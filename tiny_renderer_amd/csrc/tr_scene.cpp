@@ -146,14 +146,15 @@ struct tr_scene {
     hipEvent_t ev_tile[RING] = {};
     uint64_t pass_seq = 0;
     struct PendingTile {
-        int fs, tile_waves, kernel_id;
+        int fs, tile_waves, shared, kernel_id;
         uint64_t p_seq;
         TileArgs args;
     };
     std::vector<PendingTile> pending;  // passes whose setup is queued and whose tile kernel is not yet
     uint64_t tiles_submitted = 0;      // tile kernels handed to the main stream so far
     uint64_t last_submitted_seq = 0;   // pass number of the newest of them (its ev_tile tells whether the stream is idle)
-    uint32_t tile_waves = 0;     // tr_options.tile_waves: 4, 8 or 0 = by tile count
+    uint32_t tile_waves = 0;     // tr_options.tile_waves: 4, 8, 16 or 0 = by tile count
+    uint32_t tile_mode = 0;      // tr_options.tile_mode: 1 columns, 2 shared bin, 0 = automatic
     uint32_t bin_cap = 0;        // records per tile; grown on overflow
     uint32_t rec_pieces = 0;
     uint32_t *d_bin_need = nullptr;
@@ -327,11 +328,11 @@ int submit_pending(tr_scene *s)
     int status = TR_OK;
     for (const tr_scene::PendingTile &t : s->pending) {
         if (!s->profiling) {
-            int rc = launch_tile(t.fs, t.args, t.tile_waves, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
+            int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
             if (rc && status == TR_OK) status = launch_status(rc, "k_tile");
         } else {
             EventPair ep = { take_event(s), take_event(s), t.kernel_id };
-            int rc = launch_tile(t.fs, t.args, t.tile_waves, s->stream, ep.a, ep.b);
+            int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, ep.a, ep.b);
             if (rc && status == TR_OK) status = launch_status(rc, "k_tile");
             s->events.push_back(ep);
             if (hipEventRecord(s->ev_tile[t.p_seq % RING], s->stream) != hipSuccess && status == TR_OK)
@@ -395,6 +396,14 @@ int materialize_depth(tr_scene *s)
 }
 
 int render_frame(tr_scene *s);
+
+// How the waves of a tile divide the work when tr_options.tile_mode leaves it open (speed only).
+int tile_mode_auto(int by_tile_count)
+{
+    static const int forced = getenv("TR_TILE_MODE") ? atoi(getenv("TR_TILE_MODE")) : 0;  // test hook: 1 columns, 2 shared
+    if (forced == 1 || forced == 2) return forced == 2;
+    return by_tile_count;
+}
 
 // A tile received more polygons than its bin holds (k_tile then works on the first bin_cap records
 // only: a truncated frame).  Grow the bins to what the passes asked for, then:
@@ -604,14 +613,19 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
-    // More waves per tile shorten the serial work of each and multiply the waves a tile brings:
-    // faster while the tiles with polygons cannot fill the GPU (1536 workgroup slots at four waves),
-    // slower beyond (more total work).  Measured on diablo (k_tile, us, 4 / 8 / 16 waves): 800^2
-    // 97 / 65 / 46, 1024^2 76 / 53 / 37, 2048^2 42 / 31 / 27, 4096^2 36 / 44 / 74.
-    const int tile_waves = s->tile_waves ? (int)s->tile_waves : n_tiles_pass <= 2048u ? 16 : n_tiles_pass <= 4096u ? 8 : 4;
+    // How a tile's work is divided is a launch-time choice (speed only; tr_options.tile_waves / tile_mode
+    // pin it).  Few tiles cannot fill the GPU with four waves each: more waves per tile shorten every
+    // wave's serial chain, and sharing the bin between them (instead of giving each a column of the
+    // tile) keeps them equally loaded where polygons cluster.  Many tiles fill the GPU anyway: four
+    // waves with private columns do the least total work.  Measured on diablo / phong (k_tile us, best
+    // of the six combinations per size, profiles/r02_notes.md): 512^2 24.8 (16 shared; 4 columns 129),
+    // 1024^2 22.2 (16 shared), 2048^2 21.9 (8 shared), 2560^2 23.2 (8 columns), 4096^2 33.1 (4 columns).
+    const int tile_waves = s->tile_waves ? (int)s->tile_waves : n_tiles_pass <= 1024u ? 16 : n_tiles_pass <= 4608u ? 8 : 4;
+    const int shared_auto = n_tiles_pass <= 2048u ? 1 : 0;
     tr_scene::PendingTile pt;
     pt.fs = p.fs;
     pt.tile_waves = tile_waves;
+    pt.shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto(shared_auto);
     pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
     pt.p_seq = p_seq;
     pt.args = ta;
@@ -739,6 +753,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     if (o.tile_waves != 0 && o.tile_waves != 4 && o.tile_waves != 8 && o.tile_waves != 16)
         return tr::fail(TR_E_INVALID, "tile_waves must be 0, 4, 8 or 16");
     s->tile_waves = o.tile_waves;
+    if (o.tile_mode > 2) return tr::fail(TR_E_INVALID, "tile_mode must be 0 (automatic), 1 (columns) or 2 (shared bin)");
+    s->tile_mode = o.tile_mode;
 
     if (o.stream) {
         s->stream = (hipStream_t)o.stream;

@@ -38,7 +38,7 @@ class Scene:
 
     def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
                  winner_tap=False, tile_stamps=False, band_rows=None, stream=None, frame_buffer_device=None,
-                 bin_capacity=0, tile_waves=0):
+                 bin_capacity=0, tile_waves=0, tile_mode=0):
         L = load_library()
         self.width, self.height = int(width), int(height)
         keep = []
@@ -60,6 +60,7 @@ class Scene:
         o.frame_buffer_device = frame_buffer_device
         o.bin_capacity = int(bin_capacity)
         o.tile_waves = int(tile_waves)
+        o.tile_mode = int(tile_mode)
         h = C.c_void_p()
         self._h = None
         self._pinned = []
