@@ -379,9 +379,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
 {
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
-    constexpr int QUAD = SHARED ? TILE_W : TILE_W / TILE_WAVES;  // width of the region a wave resolves
-    constexpr int NBX = QUAD / 8;              // 8x8 lane blocks per quadrant row
-    constexpr int QPIX = QUAD * TILE_H;
+    constexpr int QUAD_COLUMN = TILE_W / TILE_WAVES;  // width of a wave's column when columns are owned
     constexpr int WAVES_PER_STRIP = TILE_WAVES / (TILE_W / STRIP);  // shading: waves sharing a 32-pixel strip
     constexpr int STRIP_ROWS = TILE_H / WAVES_PER_STRIP;            // rows of the strip each of them shades
     static_assert(STRIP_ROWS % 4 == 0, "a shading step covers four rows");
@@ -442,217 +440,235 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // is every z of this tile logically f32::MIN (cleared frame, or fast-clear flag still set)?
     // then nothing is read and every live z is written, after which the flag is down
     const bool zfresh = a.fresh || (a.zclean && a.zclean[tile] != 0u);
-    const int32_t qx0 = SHARED ? tile_x0 : tile_x0 + (int32_t)wave * QUAD, qy0 = tile_y0;
-    uint2 *wkey = SHARED ? s_key : s_key + wave * QPIX;
+    const int32_t qy0 = tile_y0;
     constexpr uint32_t PREV_TAG = DEPTH ? 0u : 0xFFFFFFFFu;  // shared mode: tie-break word of the buffer's old content
+    // A launch compiled for the shared resolve still gives tiles with few polygons to the column form:
+    // sharing deals whole polygons to waves, and four polygons that each cross the entire tile would
+    // occupy four waves for 16 column pairs each while the others idle (2048^2: such tiles were the
+    // slowest of the frame, 19-21 us); columns split exactly that work evenly.
+    const bool shared_tile = SHARED && n >= 2u * (uint32_t)TILE_WAVES;
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     const uint4 *bin = reinterpret_cast<const uint4 *>(a.bins) + (size_t)tile * a.bin_cap * P;
     const bool resident = n <= (uint32_t)NMAX;  // the whole bin stays in LDS through shading
 
-    // ---- initial keys -------------------------------------------------------------------
-    if (SHARED) {
-        // the waves initialise the tile's blocks between them (block b of the block-major key array)
-        for (int b = (int)wave; b < NBX * NBY; b += TILE_WAVES) {
-            uint32_t zb = TR_F32_MIN_BITS;
-            if (!zfresh) {
-                const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
-                if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
-                    zb = __float_as_uint(depth[(size_t)py * W + px]);
+    // ---- initial keys, coverage + depth resolve: one body for both forms ------------------------
+    auto resolve = [&](auto shared_tag) {
+        constexpr bool SH = decltype(shared_tag)::value;
+        constexpr int QUAD = SH ? TILE_W : QUAD_COLUMN;  // width of the region a wave resolves
+        constexpr int NBX = QUAD / 8;                    // 8x8 lane blocks per row of it
+        constexpr int QPIX = QUAD * TILE_H;
+        const int32_t qx0 = SH ? tile_x0 : tile_x0 + (int32_t)wave * QUAD;
+        uint2 *wkey = SH ? s_key : s_key + wave * QPIX;
+        // ---- initial keys -------------------------------------------------------------------
+        if (SH) {
+            // the waves initialise the tile's blocks between them (block b of the block-major key array)
+            for (int b = (int)wave; b < NBX * NBY; b += TILE_WAVES) {
+                uint32_t zb = TR_F32_MIN_BITS;
+                if (!zfresh) {
+                    const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
+                    if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
+                        zb = __float_as_uint(depth[(size_t)py * W + px]);
+                }
+                wkey[(b << 6) + lane] = make_uint2(PREV_TAG, depth_order_bits(__uint_as_float(zb)));
             }
-            wkey[(b << 6) + lane] = make_uint2(PREV_TAG, depth_order_bits(__uint_as_float(zb)));
+        } else {
+    #pragma unroll
+            for (int b = 0; b < NBX * NBY; b++) {
+                uint32_t zb = TR_F32_MIN_BITS;
+                if (!zfresh) {
+                    const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
+                    if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
+                        zb = __float_as_uint(depth[(size_t)py * W + px]);
+                }
+                wkey[(b << 6) + lane] = make_uint2(zb, 0u);
+            }
         }
-    } else {
-#pragma unroll
-        for (int b = 0; b < NBX * NBY; b++) {
-            uint32_t zb = TR_F32_MIN_BITS;
-            if (!zfresh) {
-                const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
-                if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
-                    zb = __float_as_uint(depth[(size_t)py * W + px]);
-            }
-            wkey[(b << 6) + lane] = make_uint2(zb, 0u);
-        }
-    }
 
-    // ---- coverage + depth resolve ---------------------------------------------------------
-    // The bin (n records of P 16-byte pieces, contiguous) is copied to LDS by all 256 threads,
-    // NMAX records at a time.  Each wave then takes 64 records at a time into registers (lane l
-    // holds the raster part of record l), ballots which of them touch its quadrant and walks
-    // those, broadcasting a record to the scalar registers with v_readlane: no memory access at
-    // all per polygon.
-    for (uint32_t c0 = 0; c0 < n; c0 += NMAX) {
-        const uint32_t m = min((uint32_t)NMAX, n - c0);
-        if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
-        for (uint32_t q = tid; q < m * P; q += (uint32_t)TILE_THREADS) s_rec[q] = bin[(size_t)c0 * P + q];
-        __syncthreads();
-        if (a.stamps && c0 == 0u) t_staged = wall_clock64();
+        // ---- coverage + depth resolve ---------------------------------------------------------
+        // The bin (n records of P 16-byte pieces, contiguous) is copied to LDS by all 256 threads,
+        // NMAX records at a time.  Each wave then takes 64 records at a time into registers (lane l
+        // holds the raster part of record l), ballots which of them touch its quadrant and walks
+        // those, broadcasting a record to the scalar registers with v_readlane: no memory access at
+        // all per polygon.
+        for (uint32_t c0 = 0; c0 < n; c0 += NMAX) {
+            const uint32_t m = min((uint32_t)NMAX, n - c0);
+            if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
+            for (uint32_t q = tid; q < m * P; q += (uint32_t)TILE_THREADS) s_rec[q] = bin[(size_t)c0 * P + q];
+            __syncthreads();
+            if (a.stamps && c0 == 0u) t_staged = wall_clock64();
 
-        // column mode: every wave takes all m records, 64 per round; shared mode: record jj belongs to
-        // wave jj mod TILE_WAVES, a round covers 64 * TILE_WAVES records
-        for (uint32_t j0 = 0; j0 < m; j0 += SHARED ? 64u * (uint32_t)TILE_WAVES : 64u) {
-            const uint32_t jj = SHARED ? j0 + lane * (uint32_t)TILE_WAVES + wave : j0 + lane;
-            uint4 r0 = make_uint4(1u, 0u, 1u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
-            uint32_t ry = 0u;
-            if (jj < m) {
-                r0 = s_rec[jj * P + 0];
-                r1 = s_rec[jj * P + 1];
-                r2 = s_rec[jj * P + 2];
-                r3 = s_rec[jj * P + 3];
-                ry = s_rec[jj * P + (P - 1)].w;
-            }
-            // The polygon's part of to_barycentric_coord (scene.rs:178-187), for the 64 records
-            // of this round at once (lane l = record l).  Orientation is normalised so that
-            // cross.z > 0: negating a0, a1, b0, b1 flips the sign of cross.x and cross.y exactly,
-            // and dividing them by -cross.z (reciprocal -y) gives bit-identical quotients, so one
-            // branch-free form of the inside test serves both windings.
-            float la0 = __uint_as_float(r1.z), la1 = __uint_as_float(r2.x);
-            float lb0 = __uint_as_float(r1.w), lb1 = __uint_as_float(r2.y);
-            float lcz = la0 * lb1 - la1 * lb0;
-            float lry = __uint_as_float(ry);
-            if (lcz < 0.0f) {
-                la0 = -la0; la1 = -la1; lb0 = -lb0; lb1 = -lb1;
-                lcz = -lcz;
-                lry = -lry;
-            }
-            // Which 8x8 blocks of this wave's quadrant (4 columns x 2 rows; bit i + 4 j) can hold a
-            // fragment of polygon l?  Its clamped box must meet the block, and the block must not lie
-            // wholly outside one of the three edges: cross.x, cross.y and cross.z - (cross.x + cross.y)
-            // are linear in the pixel, so their largest value over a block is the value at its origin
-            // plus 7 (|d/dx|+ + |d/dy|+).  A block is dropped only when that maximum misses zero by more
-            // than a bound on the f32 rounding of both this estimate and the per-pixel evaluation, so no
-            // pixel the exact test accepts is lost (the estimate may use fused operations: it decides
-            // nothing else).  Polygons without a live block are never visited, dead column pairs of
-            // the others are skipped: 134 K -> about 70 K block pairs at diablo 4096^2.
-            uint32_t lmask = 0u;
-            {
-                const float ox = (float)isub((int32_t)r1.x, qx0), oy = (float)isub((int32_t)r1.y, qy0);
-                const float e0x = lb1, e0y = -la1, e1x = -lb0, e1y = la0;
-                const float e2x = lb0 - lb1, e2y = la1 - la0;
-                const float e0 = la1 * oy - ox * lb1, e1 = ox * lb0 - la0 * oy;
-                const float e2 = lcz - (e0 + e1);
-                const float margin = 4.76837158e-7f /* 2^-21 */ *
-                                     (((fabsf(la1) + fabsf(la0)) * (fabsf(oy) + 16.0f) +
-                                       (fabsf(lb1) + fabsf(lb0)) * (fabsf(ox) + 32.0f)) + lcz);
-                const float m0 = e0 + (7.0f * (fmaxf(e0x, 0.0f) + fmaxf(e0y, 0.0f)) + margin);
-                const float m1 = e1 + (7.0f * (fmaxf(e1x, 0.0f) + fmaxf(e1y, 0.0f)) + margin);
-                const float m2 = e2 + (7.0f * (fmaxf(e2x, 0.0f) + fmaxf(e2y, 0.0f)) + 2.0f * margin);
-#pragma unroll
-                for (int j = 0; j < NBY; j++) {
-                    const bool rows = (int32_t)r0.z <= qy0 + 8 * j + 7 && (int32_t)r0.w >= qy0 + 8 * j;
-                    const float n0 = __builtin_fmaf(8.0f * j, e0y, m0), n1 = __builtin_fmaf(8.0f * j, e1y, m1);
-                    const float n2 = __builtin_fmaf(8.0f * j, e2y, m2);
-#pragma unroll 4
-                    for (int i = 0; i < NBX; i++) {
-                        const bool cols = (int32_t)r0.x <= qx0 + 8 * i + 7 && (int32_t)r0.y >= qx0 + 8 * i;
-                        const bool alive = rows && cols && __builtin_fmaf(8.0f * i, e0x, n0) >= 0.0f &&
-                                           __builtin_fmaf(8.0f * i, e1x, n1) >= 0.0f &&
-                                           __builtin_fmaf(8.0f * i, e2x, n2) >= 0.0f;
-                        lmask |= alive ? 1u << (i + NBX * j) : 0u;
+            // column mode: every wave takes all m records, 64 per round; shared mode: record jj belongs to
+            // wave jj mod TILE_WAVES, a round covers 64 * TILE_WAVES records
+            for (uint32_t j0 = 0; j0 < m; j0 += SH ? 64u * (uint32_t)TILE_WAVES : 64u) {
+                const uint32_t jj = SH ? j0 + lane * (uint32_t)TILE_WAVES + wave : j0 + lane;
+                uint4 r0 = make_uint4(1u, 0u, 1u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
+                uint32_t ry = 0u;
+                if (jj < m) {
+                    r0 = s_rec[jj * P + 0];
+                    r1 = s_rec[jj * P + 1];
+                    r2 = s_rec[jj * P + 2];
+                    r3 = s_rec[jj * P + 3];
+                    ry = s_rec[jj * P + (P - 1)].w;
+                }
+                // The polygon's part of to_barycentric_coord (scene.rs:178-187), for the 64 records
+                // of this round at once (lane l = record l).  Orientation is normalised so that
+                // cross.z > 0: negating a0, a1, b0, b1 flips the sign of cross.x and cross.y exactly,
+                // and dividing them by -cross.z (reciprocal -y) gives bit-identical quotients, so one
+                // branch-free form of the inside test serves both windings.
+                float la0 = __uint_as_float(r1.z), la1 = __uint_as_float(r2.x);
+                float lb0 = __uint_as_float(r1.w), lb1 = __uint_as_float(r2.y);
+                float lcz = la0 * lb1 - la1 * lb0;
+                float lry = __uint_as_float(ry);
+                if (lcz < 0.0f) {
+                    la0 = -la0; la1 = -la1; lb0 = -lb0; lb1 = -lb1;
+                    lcz = -lcz;
+                    lry = -lry;
+                }
+                // Which 8x8 blocks of this wave's quadrant (4 columns x 2 rows; bit i + 4 j) can hold a
+                // fragment of polygon l?  Its clamped box must meet the block, and the block must not lie
+                // wholly outside one of the three edges: cross.x, cross.y and cross.z - (cross.x + cross.y)
+                // are linear in the pixel, so their largest value over a block is the value at its origin
+                // plus 7 (|d/dx|+ + |d/dy|+).  A block is dropped only when that maximum misses zero by more
+                // than a bound on the f32 rounding of both this estimate and the per-pixel evaluation, so no
+                // pixel the exact test accepts is lost (the estimate may use fused operations: it decides
+                // nothing else).  Polygons without a live block are never visited, dead column pairs of
+                // the others are skipped: 134 K -> about 70 K block pairs at diablo 4096^2.
+                uint32_t lmask = 0u;
+                {
+                    const float ox = (float)isub((int32_t)r1.x, qx0), oy = (float)isub((int32_t)r1.y, qy0);
+                    const float e0x = lb1, e0y = -la1, e1x = -lb0, e1y = la0;
+                    const float e2x = lb0 - lb1, e2y = la1 - la0;
+                    const float e0 = la1 * oy - ox * lb1, e1 = ox * lb0 - la0 * oy;
+                    const float e2 = lcz - (e0 + e1);
+                    const float margin = 4.76837158e-7f /* 2^-21 */ *
+                                         (((fabsf(la1) + fabsf(la0)) * (fabsf(oy) + 16.0f) +
+                                           (fabsf(lb1) + fabsf(lb0)) * (fabsf(ox) + 32.0f)) + lcz);
+                    const float m0 = e0 + (7.0f * (fmaxf(e0x, 0.0f) + fmaxf(e0y, 0.0f)) + margin);
+                    const float m1 = e1 + (7.0f * (fmaxf(e1x, 0.0f) + fmaxf(e1y, 0.0f)) + margin);
+                    const float m2 = e2 + (7.0f * (fmaxf(e2x, 0.0f) + fmaxf(e2y, 0.0f)) + 2.0f * margin);
+    #pragma unroll
+                    for (int j = 0; j < NBY; j++) {
+                        const bool rows = (int32_t)r0.z <= qy0 + 8 * j + 7 && (int32_t)r0.w >= qy0 + 8 * j;
+                        const float n0 = __builtin_fmaf(8.0f * j, e0y, m0), n1 = __builtin_fmaf(8.0f * j, e1y, m1);
+                        const float n2 = __builtin_fmaf(8.0f * j, e2y, m2);
+    #pragma unroll 4
+                        for (int i = 0; i < NBX; i++) {
+                            const bool cols = (int32_t)r0.x <= qx0 + 8 * i + 7 && (int32_t)r0.y >= qx0 + 8 * i;
+                            const bool alive = rows && cols && __builtin_fmaf(8.0f * i, e0x, n0) >= 0.0f &&
+                                               __builtin_fmaf(8.0f * i, e1x, n1) >= 0.0f &&
+                                               __builtin_fmaf(8.0f * i, e2x, n2) >= 0.0f;
+                            lmask |= alive ? 1u << (i + NBX * j) : 0u;
+                        }
                     }
                 }
-            }
-            const bool touch = lmask != 0u;
-            unsigned long long todo = __ballot(touch);
-            while (todo) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const int32_t bx0 = imax(bcast(r0.x, l), qx0), bx1 = imin(bcast(r0.y, l), qx0 + QUAD - 1);
-                const int32_t by0 = imax(bcast(r0.z, l), qy0), by1 = imin(bcast(r0.w, l), qy0 + TILE_H - 1);
-                const int32_t x0 = bcast(r1.x, l), y0 = bcast(r1.y, l);
-                const float z0 = __int_as_float(bcast(r2.z, l)), z1 = __int_as_float(bcast(r2.w, l));
-                const float z2 = __int_as_float(bcast(r3.x, l));
-                const uint32_t id = (uint32_t)bcast(r3.y, l);
-                const uint32_t slot1 = SHARED ? c0 + j0 + l * (uint32_t)TILE_WAVES + wave + 1u : c0 + j0 + l + 1u;
-                const uint32_t live_blocks = (uint32_t)bcast(lmask, l);
-                Edge2 e;
-                e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
-                e.a1 = splat2(__int_as_float(bcast(__float_as_uint(la1), l)));
-                e.b0 = splat2(__int_as_float(bcast(__float_as_uint(lb0), l)));
-                e.b1 = splat2(__int_as_float(bcast(__float_as_uint(lb1), l)));
-                const float cz = __int_as_float(bcast(__float_as_uint(lcz), l));
-                e.cz = splat2(cz);
-                e.y = splat2(__int_as_float(bcast(__float_as_uint(lry), l)));
-                // this lane's two pixels: (px, pya) in block row 0 and (px, pyb) in block row 1
-                const int32_t pya = qy0 + ly, pyb = qy0 + 8 + ly;
-                const f2 b2 = mk2((float)isub(y0, pya), (float)isub(y0, pyb));
-                // the inside test (scene.rs:245-247 on to_barycentric_coord's cross products, divided
-                // by cross.z > 0): cross.x >= 0, cross.y >= 0, cross.x + cross.y <= cross.z.  The last is
-                // taken as cross.z - (cross.x + cross.y) >= 0 (same truth value: a difference of two
-                // floats has the sign of the exact difference) so that one three-way minimum and one
-                // compare decide a pixel; a row outside the clamped box gets -inf for cross.z.
-                const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
-                const f2 czp = mk2(rowa ? cz : -__builtin_inff(), rowb ? cz : -__builtin_inff());
-                const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
-                // column pairs inside the box with a live block
-                uint32_t cols = (live_blocks | (live_blocks >> NBX)) & ((2u << ib1) - (1u << ib0));
-                while (cols) {
-                    const int32_t ib = (int32_t)__builtin_ctz(cols);
-                    cols &= cols - 1u;
-                    // the two pixels' current keys, requested before the arithmetic that decides
-                    // whether they are needed (LDS latency hidden inside the wave)
-                    uint2 *slot_a = wkey + ((ib << 6) + (int32_t)lane), *slot_b = slot_a + (NBX << 6);
-                    const uint2 cur_a = *slot_a, cur_b = *slot_b;
-                    const int32_t px = qx0 + ib * 8 + lx;
-                    const bool inx = (uint32_t)isub(px, bx0) <= (uint32_t)isub(bx1, bx0);
-                    f2 cx, cy;
-                    edge_cross2(e, splat2((float)isub(x0, px)), b2, cx, cy);
-                    const f2 rest = czp - (cx + cy);
-                    const bool hita = inx && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
-                    const bool hitb = inx && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
-                    if (SHARED) {
-                        if (hita || hitb) {
-                            // shared keys: the candidate (depth order bits, tie-break word) against what the
-                            // pixel holds now -- a plain read, possibly stale, but keys only grow, so a
-                            // candidate that does not beat it can never win -- then one atomic maximum
+                const bool touch = lmask != 0u;
+                unsigned long long todo = __ballot(touch);
+                while (todo) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const int32_t bx0 = imax(bcast(r0.x, l), qx0), bx1 = imin(bcast(r0.y, l), qx0 + QUAD - 1);
+                    const int32_t by0 = imax(bcast(r0.z, l), qy0), by1 = imin(bcast(r0.w, l), qy0 + TILE_H - 1);
+                    const int32_t x0 = bcast(r1.x, l), y0 = bcast(r1.y, l);
+                    const float z0 = __int_as_float(bcast(r2.z, l)), z1 = __int_as_float(bcast(r2.w, l));
+                    const float z2 = __int_as_float(bcast(r3.x, l));
+                    const uint32_t id = (uint32_t)bcast(r3.y, l);
+                    const uint32_t slot1 = SH ? c0 + j0 + l * (uint32_t)TILE_WAVES + wave + 1u : c0 + j0 + l + 1u;
+                    const uint32_t live_blocks = (uint32_t)bcast(lmask, l);
+                    Edge2 e;
+                    e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
+                    e.a1 = splat2(__int_as_float(bcast(__float_as_uint(la1), l)));
+                    e.b0 = splat2(__int_as_float(bcast(__float_as_uint(lb0), l)));
+                    e.b1 = splat2(__int_as_float(bcast(__float_as_uint(lb1), l)));
+                    const float cz = __int_as_float(bcast(__float_as_uint(lcz), l));
+                    e.cz = splat2(cz);
+                    e.y = splat2(__int_as_float(bcast(__float_as_uint(lry), l)));
+                    // this lane's two pixels: (px, pya) in block row 0 and (px, pyb) in block row 1
+                    const int32_t pya = qy0 + ly, pyb = qy0 + 8 + ly;
+                    const f2 b2 = mk2((float)isub(y0, pya), (float)isub(y0, pyb));
+                    // the inside test (scene.rs:245-247 on to_barycentric_coord's cross products, divided
+                    // by cross.z > 0): cross.x >= 0, cross.y >= 0, cross.x + cross.y <= cross.z.  The last is
+                    // taken as cross.z - (cross.x + cross.y) >= 0 (same truth value: a difference of two
+                    // floats has the sign of the exact difference) so that one three-way minimum and one
+                    // compare decide a pixel; a row outside the clamped box gets -inf for cross.z.
+                    const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
+                    const f2 czp = mk2(rowa ? cz : -__builtin_inff(), rowb ? cz : -__builtin_inff());
+                    const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
+                    // column pairs inside the box with a live block
+                    uint32_t cols = (live_blocks | (live_blocks >> NBX)) & ((2u << ib1) - (1u << ib0));
+                    while (cols) {
+                        const int32_t ib = (int32_t)__builtin_ctz(cols);
+                        cols &= cols - 1u;
+                        // the two pixels' current keys, requested before the arithmetic that decides
+                        // whether they are needed (LDS latency hidden inside the wave)
+                        uint2 *slot_a = wkey + ((ib << 6) + (int32_t)lane), *slot_b = slot_a + (NBX << 6);
+                        const uint2 cur_a = *slot_a, cur_b = *slot_b;
+                        const int32_t px = qx0 + ib * 8 + lx;
+                        const bool inx = (uint32_t)isub(px, bx0) <= (uint32_t)isub(bx1, bx0);
+                        f2 cx, cy;
+                        edge_cross2(e, splat2((float)isub(x0, px)), b2, cx, cy);
+                        const f2 rest = czp - (cx + cy);
+                        const bool hita = inx && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
+                        const bool hitb = inx && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
+                        if (SH) {
+                            if (hita || hitb) {
+                                // shared keys: the candidate (depth order bits, tie-break word) against what the
+                                // pixel holds now -- a plain read, possibly stale, but keys only grow, so a
+                                // candidate that does not beat it can never win -- then one atomic maximum
+                                const Bary2 bar = barycentric2_for_compare(cx, cy, e);
+                                const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
+                                const uint32_t tag = (((SHARED_MAX_POLYGONS - 1u) - id) << 12) | slot1;
+                                const unsigned long long ka = ((unsigned long long)depth_order_bits(z.x) << 32) | tag;
+                                const unsigned long long kb = ((unsigned long long)depth_order_bits(z.y) << 32) | tag;
+                                const unsigned long long ca_ = ((unsigned long long)cur_a.y << 32) | cur_a.x;
+                                const unsigned long long cb_ = ((unsigned long long)cur_b.y << 32) | cur_b.x;
+                                if (hita && ka > ca_)
+                                    __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot_a), ka, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (hitb && kb > cb_)
+                                    __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot_b), kb, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        } else if (hita || hitb) {
+                            // depth of both fragments; only compared here (the survivor's stored z is
+                            // recomputed with exact zero signs when it is shaded)
                             const Bary2 bar = barycentric2_for_compare(cx, cy, e);
                             const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
-                            const uint32_t tag = (((SHARED_MAX_POLYGONS - 1u) - id) << 12) | slot1;
-                            const unsigned long long ka = ((unsigned long long)depth_order_bits(z.x) << 32) | tag;
-                            const unsigned long long kb = ((unsigned long long)depth_order_bits(z.y) << 32) | tag;
-                            const unsigned long long ca_ = ((unsigned long long)cur_a.y << 32) | cur_a.x;
-                            const unsigned long long cb_ = ((unsigned long long)cur_b.y << 32) | cur_b.x;
-                            if (hita && ka > ca_)
-                                __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot_a), ka, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (hitb && kb > cb_)
-                                __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot_b), kb, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    } else if (hita || hitb) {
-                        // depth of both fragments; only compared here (the survivor's stored z is
-                        // recomputed with exact zero signs when it is shaded)
-                        const Bary2 bar = barycentric2_for_compare(cx, cy, e);
-                        const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
-                        // both comparisons first, branch-free, so that the two key reads above are
-                        // consumed together after the arithmetic; equal depths (shared vertices and
-                        // edges, or the buffer's previous content) are the rare divergent path
-                        const float zca = __uint_as_float(cur_a.x), zcb = __uint_as_float(cur_b.x);
-                        bool wina = hita && z.x > zca, winb = hitb && z.y > zcb;
-                        const bool tiea = hita && z.x == zca, tieb = hitb && z.y == zcb;
-                        if (tiea || tieb) {
-                            // equal depth: the buffer's previous content beats a colour fragment
-                            // (`z <= zbuf` rejects) and loses to a depth fragment (`z >= shadow`
-                            // accepts); between two fragments of this pass the polygon index decides
-#pragma unroll
-                            for (int h = 0; h < 2; h++) {
-                                if (!(h == 0 ? tiea : tieb)) continue;
-                                const uint32_t cs = h == 0 ? cur_a.y : cur_b.y;
-                                bool w = DEPTH;
-                                if (cs != 0u) {
-                                    const uint32_t cur_id = resident ? s_rec[(cs - 1u) * P + 3].y
-                                                                     : bin[(size_t)(cs - 1u) * P + 3].y;
-                                    w = DEPTH ? id > cur_id : id < cur_id;
+                            // both comparisons first, branch-free, so that the two key reads above are
+                            // consumed together after the arithmetic; equal depths (shared vertices and
+                            // edges, or the buffer's previous content) are the rare divergent path
+                            const float zca = __uint_as_float(cur_a.x), zcb = __uint_as_float(cur_b.x);
+                            bool wina = hita && z.x > zca, winb = hitb && z.y > zcb;
+                            const bool tiea = hita && z.x == zca, tieb = hitb && z.y == zcb;
+                            if (tiea || tieb) {
+                                // equal depth: the buffer's previous content beats a colour fragment
+                                // (`z <= zbuf` rejects) and loses to a depth fragment (`z >= shadow`
+                                // accepts); between two fragments of this pass the polygon index decides
+    #pragma unroll
+                                for (int h = 0; h < 2; h++) {
+                                    if (!(h == 0 ? tiea : tieb)) continue;
+                                    const uint32_t cs = h == 0 ? cur_a.y : cur_b.y;
+                                    bool w = DEPTH;
+                                    if (cs != 0u) {
+                                        const uint32_t cur_id = resident ? s_rec[(cs - 1u) * P + 3].y
+                                                                         : bin[(size_t)(cs - 1u) * P + 3].y;
+                                        w = DEPTH ? id > cur_id : id < cur_id;
+                                    }
+                                    if (h == 0) wina = w; else winb = w;
                                 }
-                                if (h == 0) wina = w; else winb = w;
                             }
+                            if (wina) *slot_a = make_uint2(__float_as_uint(z.x), slot1);
+                            if (winb) *slot_b = make_uint2(__float_as_uint(z.y), slot1);
                         }
-                        if (wina) *slot_a = make_uint2(__float_as_uint(z.x), slot1);
-                        if (winb) *slot_b = make_uint2(__float_as_uint(z.y), slot1);
                     }
                 }
             }
         }
-    }
+
+    };
+    if (shared_tile)
+        resolve(std::bool_constant<SHARED>{});
+    else
+        resolve(std::false_type{});
 
     uint64_t t_covered = 0;
     if (a.stamps) t_covered = wall_clock64();
@@ -667,7 +683,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // Addresses are a per-wave base (scalar registers) plus a 32-bit lane offset built with 24-bit
     // multiplies: 64-bit and 32 x 32 multiplies run at quarter rate and were a third of this
     // phase's vector-ALU time.
-    if (SHARED || TILE_WAVES != TILE_W / STRIP) __syncthreads();  // a strip holds pixels other waves resolved
+    if (SHARED || TILE_WAVES != TILE_W / STRIP) __syncthreads();  // a strip may hold pixels other waves resolved
     const int32_t hx = (int32_t)(lane & 31u), hrow = (int32_t)(lane >> 5);
     const uint32_t half_base = lane & 32u;
     const int32_t strip_x = (int32_t)(wave / (uint32_t)WAVES_PER_STRIP) * STRIP;  // within the tile
@@ -700,12 +716,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             py[u] = sy0 + row[u];
             live[u] = col_live && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
             uint32_t s1;
-            if (SHARED) {
+            if (SHARED && shared_tile) {
                 // tie-break word: low 12 bits = bin slot + 1 of a fragment, 0xFFF / 0 = the buffer's old content
-                const uint32_t f = s_key[key_slot<QUAD>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].x & 0xFFFu;
+                const uint32_t f = s_key[key_slot<TILE_W>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].x & 0xFFFu;
                 s1 = (f == 0xFFFu) ? 0u : f;
             } else {
-                s1 = s_key[key_slot<QUAD>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
+                s1 = s_key[key_slot<QUAD_COLUMN>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
             }
             won[u] = live[u] && s1 != 0u;
             wslot[u] = won[u] ? s1 - 1u : 0u;
