@@ -397,6 +397,10 @@ int materialize_depth(tr_scene *s)
 
 int render_frame(tr_scene *s);
 
+// Tiles the bins must cover: a band scene's colour passes touch its own rows only; the depth passes of
+// shadow / occlusion fill the whole shadow buffer on every rank (shader.rs:774-778).
+uint32_t bin_tiles(const tr_scene *s) { return kPipelines[s->pipeline].n_passes == 2 ? s->n_tiles_full : s->n_tiles; }
+
 // How the waves of a tile divide the work when tr_options.tile_mode leaves it open (speed only).
 int tile_mode_auto(int by_tile_count)
 {
@@ -423,14 +427,14 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     while (cap < need) cap *= 2;
     if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
     if (cap < need) cap = need;
-    if ((uint64_t)LOOKAHEAD * cap * (uint64_t)s->n_tiles_full * s->rec_pieces * 16ull > (64ull << 30))
+    if ((uint64_t)LOOKAHEAD * cap * (uint64_t)bin_tiles(s) * s->rec_pieces * 16ull > (64ull << 30))
         return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 64 GiB");
     HIP_TRY(hipStreamSynchronize(s->setup_stream));
     s->bin_cap = (uint32_t)cap;
     int st = TR_OK;
     for (int k = 0; k < LOOKAHEAD && st == TR_OK; k++) {
         dev_free(s->d_bins[k]);
-        st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces);
+        st = dev_alloc(&s->d_bins[k], (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces);
     }
     if (st != TR_OK) return st;
     if (first_bad_seq < s->observed_seq)
@@ -827,7 +831,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->bin_cap = (uint32_t)cap;
     s->rec_pieces = (pipe == P_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     for (int k = 0; k < LOOKAHEAD; k++)
-        if ((st = dev_alloc(&s->d_bins[k], (size_t)s->n_tiles_full * s->bin_cap * s->rec_pieces))) return st;
+        if ((st = dev_alloc(&s->d_bins[k], (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces))) return st;
     HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream, hipStreamNonBlocking));
     for (int k = 0; k < RING; k++) {
         HIP_TRY(hipEventCreateWithFlags(&s->ev_setup[k], hipEventDisableTiming));
