@@ -90,15 +90,27 @@ struct EventPair {
 // 4096^2) -- cheap next to 288 GB.
 constexpr int LOOKAHEAD = 5;
 constexpr int SETS = LOOKAHEAD + 1;
-// Tile kernels are handed to the main stream in batches of up to BATCH passes behind ONE wait for the
-// setup stream: that wait packet, sitting between two consecutive tile kernels in the same queue,
-// costs 5.5 us (two back-to-back tile kernels are 3.8 us apart, with the wait in between 9.3).  A
-// pass that is not yet in the queue is "pending": everything that touches the main stream, waits
-// for the scene or hands control to a caller-provided stream submits the pending passes first, so
-// nothing observable changes.  BATCH <= LOOKAHEAD - 1: the setup of pass p waits for the tile kernel
-// of pass p - LOOKAHEAD, which must have been submitted by then.
+// Handing tile kernels to the main stream.  The tile kernel of pass p must run after that pass's setup
+// (other stream).  A cross-stream wait packet sitting between two tile kernels in the main stream's
+// queue costs 5.5 us (two back-to-back tile kernels are 3.8 us apart, 9.3 with the wait in between), and
+// none is needed if the setup has ALREADY completed when the tile kernel is enqueued.  So a pass whose
+// setup is queued stays "pending" on the host until one of these:
+//   * more than BATCH passes are pending (the steady state of a running loop): the host waits for the
+//     oldest one's setup event itself -- it has completed or is about to, the setup stream runs ahead --
+//     and enqueues its tile kernel with no wait packet at all.  That host-side wait is also the
+//     frames-in-flight limit: render() cannot run more than BATCH + LOOKAHEAD passes ahead of the GPU;
+//   * its setup event reads complete at a later render(): out it goes, no wait (start-up);
+//   * the main stream has run dry (its newest tile kernel has completed): the oldest pending pass goes
+//     out behind a wait packet on ITS setup event -- the first frame after a sync;
+//   * anything needs the main stream or waits for the scene -- a getter, a sync, a clear that must be
+//     materialised, a read-back, destruction: everything pending goes out behind ONE wait for the newest
+//     setup (the setup stream is in order).
+// BATCH <= LOOKAHEAD - 1: the setup of pass p waits for the tile kernel of pass p - LOOKAHEAD, which must
+// have been submitted by then.  Nothing observable changes (submit_pending runs before every use of the
+// stream).  Round 1 handed over in fixed batches of four behind one wait packet: 35.2 us/frame where this
+// gives 34.2 (same box), and at small frames 25 -> 20.5 us (800^2), 24.8 -> 22.4 (2048^2).
 constexpr int BATCH = LOOKAHEAD - 1;
-constexpr int RING = LOOKAHEAD + 1;  // events: pass p's may be waited for until pass p + LOOKAHEAD is set up
+constexpr int RING = 16;  // events: pass p's are waited for until pass p + LOOKAHEAD is set up
 
 struct tr_scene {
     uint32_t width = 0, height = 0;
@@ -319,7 +331,27 @@ int launch_status(int rc, const char *what)
     return tr::fail(TR_E_HIP, std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
 }
 
-// Puts the pending tile kernels on the main stream: one wait for the setup stream (it is in order,
+// Enqueues one pending pass's tile kernel on the main stream.
+int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
+{
+    int status = TR_OK;
+    if (!s->profiling) {
+        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
+        if (rc) status = launch_status(rc, "k_tile");
+    } else {
+        EventPair ep = { take_event(s), take_event(s), t.kernel_id };
+        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, ep.a, ep.b);
+        if (rc) status = launch_status(rc, "k_tile");
+        s->events.push_back(ep);
+        if (hipEventRecord(s->ev_tile[t.p_seq % RING], s->stream) != hipSuccess && status == TR_OK)
+            status = tr::fail(TR_E_HIP, "hipEventRecord");
+    }
+    s->tiles_submitted += 1;
+    s->last_submitted_seq = t.p_seq;
+    return status;
+}
+
+// Puts ALL pending tile kernels on the main stream: one wait for the setup stream (it is in order,
 // so the newest pass's event covers the older ones), then the kernels back to back.
 int submit_pending(tr_scene *s)
 {
@@ -327,21 +359,31 @@ int submit_pending(tr_scene *s)
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[s->pending.back().p_seq % RING], 0));
     int status = TR_OK;
     for (const tr_scene::PendingTile &t : s->pending) {
-        if (!s->profiling) {
-            int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
-            if (rc && status == TR_OK) status = launch_status(rc, "k_tile");
-        } else {
-            EventPair ep = { take_event(s), take_event(s), t.kernel_id };
-            int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, ep.a, ep.b);
-            if (rc && status == TR_OK) status = launch_status(rc, "k_tile");
-            s->events.push_back(ep);
-            if (hipEventRecord(s->ev_tile[t.p_seq % RING], s->stream) != hipSuccess && status == TR_OK)
-                status = tr::fail(TR_E_HIP, "hipEventRecord");
-        }
+        int st = launch_pending_tile(s, t);
+        if (st != TR_OK && status == TR_OK) status = st;
     }
-    s->tiles_submitted += s->pending.size();
-    s->last_submitted_seq = s->pending.back().p_seq;
     s->pending.clear();
+    return status;
+}
+
+// The oldest pending pass alone, behind a wait for its own setup if that may still be running.
+int submit_front(tr_scene *s, bool wait_for_setup)
+{
+    if (s->pending.empty()) return TR_OK;
+    const tr_scene::PendingTile t = s->pending.front();
+    if (wait_for_setup) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[t.p_seq % RING], 0));
+    s->pending.erase(s->pending.begin());
+    return launch_pending_tile(s, t);
+}
+
+// Every pending pass whose setup has completed, oldest first, without any cross-stream wait.
+int submit_ready(tr_scene *s)
+{
+    int status = TR_OK;
+    while (!s->pending.empty() && hipEventQuery(s->ev_setup[s->pending.front().p_seq % RING]) == hipSuccess) {
+        int st = submit_front(s, false);
+        if (st != TR_OK && status == TR_OK) status = st;
+    }
     return status;
 }
 
@@ -642,14 +684,26 @@ int run_pass(tr_scene *s, const PassDesc &p)
         s->observed_seq = s->pass_seq;
         return submit_pending(s);
     }
-    // on the library's own stream up to BATCH passes wait for company -- but only while the main
-    // stream still has tile kernels to run: holding work back from an idle queue (the first frames
-    // after a sync) would leave the GPU waiting for the host to issue three more frames
-    static const int batch = getenv("TR_BATCH") ? atoi(getenv("TR_BATCH")) : BATCH;  // experiment hook (1..BATCH)
-    if ((int)s->pending.size() >= (batch < 1 ? 1 : batch > BATCH ? BATCH : batch)) return submit_pending(s);
-    if (s->tiles_submitted == 0 || hipEventQuery(s->ev_tile[(s->last_submitted_seq) % RING]) == hipSuccess)
-        return submit_pending(s);
-    return TR_OK;
+    // the library's own stream: see "Handing tile kernels to the main stream" above
+    int status = TR_OK;
+    if ((int)s->pending.size() > BATCH) {
+        // steady state: the HOST waits for the oldest pending pass's setup (it completed long ago, or will
+        // within microseconds: the setup stream runs ahead, and the main stream still holds the tile kernels
+        // of the passes before it), then its tile kernel goes out with no wait packet in the GPU's queue.
+        // This is also what keeps the host from running ahead of the GPU without bound.
+        while ((int)s->pending.size() > BATCH) {
+            HIP_TRY(hipEventSynchronize(s->ev_setup[s->pending.front().p_seq % RING]));
+            int st2 = submit_front(s, false);
+            if (st2 != TR_OK && status == TR_OK) status = st2;
+        }
+        return status;
+    }
+    // start-up (the first passes after a sync): a main stream that has run dry gets the next tile kernel
+    // behind a wait packet (an idle GPU loses nothing to it) ...
+    if (s->tiles_submitted == 0 || hipEventQuery(s->ev_tile[s->last_submitted_seq % RING]) == hipSuccess)
+        return submit_front(s, true);
+    // ... otherwise whatever has its setup behind it goes out without one
+    return submit_ready(s);
 }
 
 int render_frame(tr_scene *s)
