@@ -256,8 +256,9 @@ def main():
         with torch.cuda.stream(render_stream):
             if frame_no[0] > n_buf:
                 render_stream.wait_event(gathered[b])  # the exchange of the frame that used this buffer is done
-            render_started[b].record(render_stream)
-            scene.set_frame_buffer_device(fb_ptr[b])
+            if timing["on"]:
+                render_started[b].record(render_stream)   # timing events only in the profiled leg: every event
+            scene.set_frame_buffer_device(fb_ptr[b])      # packet in a queue costs a few microseconds
             scene.clear()
             scene.set_light_direction(lt)
             scene.set_camera(*cam_now)
@@ -265,7 +266,8 @@ def main():
             rendered[b].record(render_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(rendered[b])
-            gather_started[b].record(comm_stream)
+            if timing["on"]:
+                gather_started[b].record(comm_stream)
             if exchange is not None:
                 exchange.all_gather(b, rank * band_bytes, band_bytes, comm_stream.cuda_stream)
             else:
