@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                     lcz = -lcz;
                     lry = -lry;
                 }
-                // Which 8x8 blocks of this wave's quadrant (4 columns x 2 rows; bit i + 4 j) can hold a
+                // Which 8x8 blocks of this wave's region (NBX columns x 2 rows; bit i + NBX j) can hold a
                 // fragment of polygon l?  Its clamped box must meet the block, and the block must not lie
                 // wholly outside one of the three edges: cross.x, cross.y and cross.z - (cross.x + cross.y)
                 // are linear in the pixel, so their largest value over a block is the value at its origin
@@ -546,21 +546,35 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                     const float m0 = e0 + (7.0f * (fmaxf(e0x, 0.0f) + fmaxf(e0y, 0.0f)) + margin);
                     const float m1 = e1 + (7.0f * (fmaxf(e1x, 0.0f) + fmaxf(e1y, 0.0f)) + margin);
                     const float m2 = e2 + (7.0f * (fmaxf(e2x, 0.0f) + fmaxf(e2y, 0.0f)) + 2.0f * margin);
+                    // edge tests of all blocks, straight-line (no short-circuit: the compiler turned `&&` chains
+                    // into an exec-mask branch per block, a dozen scalar instructions each)
+                    uint32_t edge = 0u;
     #pragma unroll
                     for (int j = 0; j < NBY; j++) {
-                        const bool rows = (int32_t)r0.z <= qy0 + 8 * j + 7 && (int32_t)r0.w >= qy0 + 8 * j;
                         const float n0 = __builtin_fmaf(8.0f * j, e0y, m0), n1 = __builtin_fmaf(8.0f * j, e1y, m1);
                         const float n2 = __builtin_fmaf(8.0f * j, e2y, m2);
     #pragma unroll 4
                         for (int i = 0; i < NBX; i++) {
-                            const bool cols = (int32_t)r0.x <= qx0 + 8 * i + 7 && (int32_t)r0.y >= qx0 + 8 * i;
-                            const bool alive = rows && cols && __builtin_fmaf(8.0f * i, e0x, n0) >= 0.0f &&
-                                               __builtin_fmaf(8.0f * i, e1x, n1) >= 0.0f &&
-                                               __builtin_fmaf(8.0f * i, e2x, n2) >= 0.0f;
-                            lmask |= alive ? 1u << (i + NBX * j) : 0u;
+                            const float worst = __builtin_fminf(__builtin_fminf(__builtin_fmaf(8.0f * i, e0x, n0),
+                                                                                __builtin_fmaf(8.0f * i, e1x, n1)),
+                                                                __builtin_fmaf(8.0f * i, e2x, n2));
+                            edge |= worst >= 0.0f ? 1u << (i + NBX * j) : 0u;
                         }
                     }
+                    // blocks the clamped box meets: columns floor((bx0 - qx0) / 8) .. floor((bx1 - qx0) / 8), rows
+                    // likewise, cut to the region (an empty box -- a rejected record, a lane without one --
+                    // gives an empty range)
+                    const int32_t ia = imax(isub((int32_t)r0.x, qx0) >> 3, 0), ib = imin(isub((int32_t)r0.y, qx0) >> 3, NBX - 1);
+                    const int32_t ja = imax(isub((int32_t)r0.z, qy0) >> 3, 0), jb = imin(isub((int32_t)r0.w, qy0) >> 3, NBY - 1);
+                    const uint32_t colbits = (ia <= ib && (int32_t)r0.x <= (int32_t)r0.y) ? (2u << ib) - (1u << ia) : 0u;
+                    uint32_t box = 0u;
+    #pragma unroll
+                    for (int j = 0; j < NBY; j++) box |= (j >= ja && j <= jb) ? colbits << (NBX * j) : 0u;
+                    lmask = edge & box;
                 }
+                // column pairs (block rows 0 / 1 of one block column) with a live block: what a visit iterates
+                // over -- the box's column range is already in the mask
+                lmask = (lmask | (lmask >> NBX)) & ((1u << NBX) - 1u);
                 const bool touch = lmask != 0u;
                 unsigned long long todo = __ballot(touch);
                 while (todo) {
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                     const float z2 = __int_as_float(bcast(r3.x, l));
                     const uint32_t id = (uint32_t)bcast(r3.y, l);
                     const uint32_t slot1 = SH ? c0 + j0 + l * (uint32_t)TILE_WAVES + wave + 1u : c0 + j0 + l + 1u;
-                    const uint32_t live_blocks = (uint32_t)bcast(lmask, l);
+                    uint32_t cols = (uint32_t)bcast(lmask, l);
                     Edge2 e;
                     e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
                     e.a1 = splat2(__int_as_float(bcast(__float_as_uint(la1), l)));
@@ -592,9 +606,6 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                     // compare decide a pixel; a row outside the clamped box gets -inf for cross.z.
                     const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
                     const f2 czp = mk2(rowa ? cz : -__builtin_inff(), rowb ? cz : -__builtin_inff());
-                    const int32_t ib0 = (bx0 - qx0) >> 3, ib1 = (bx1 - qx0) >> 3;
-                    // column pairs inside the box with a live block
-                    uint32_t cols = (live_blocks | (live_blocks >> NBX)) & ((2u << ib1) - (1u << ib0));
                     while (cols) {
                         const int32_t ib = (int32_t)__builtin_ctz(cols);
                         cols &= cols - 1u;
