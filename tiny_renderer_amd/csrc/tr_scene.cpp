@@ -85,9 +85,9 @@ struct EventPair {
 // How many passes the setup stream may run ahead of the tile kernels: setup of pass p waits for the
 // tile kernel of pass p - LOOKAHEAD only.  With 2 the setup chain (k_setup, k_order_count,
 // k_order_place: ~35 us beside a busy machine) had to fit inside one tile kernel (~34 us) and was
-// the critical path of the frame loop; 3 gave it two (44.1 -> 42.4 us per frame); 5 allows batches of
-// four tile kernels per cross-stream wait (-> 39.0).  Costs LOOKAHEAD sets of bins (0.2 GB each at
-// 4096^2) -- cheap next to 288 GB.
+// the critical path of the frame loop; 3 gave it two (44.1 -> 42.4 us per frame); 5 lets four passes
+// wait on the host for their setups to finish, so that their tile kernels need no wait packet (below).
+// Costs LOOKAHEAD sets of bins (0.2 GB each at 4096^2) -- cheap next to 288 GB.
 constexpr int LOOKAHEAD = 5;
 constexpr int SETS = LOOKAHEAD + 1;
 // Handing tile kernels to the main stream.  The tile kernel of pass p must run after that pass's setup
@@ -109,7 +109,7 @@ constexpr int SETS = LOOKAHEAD + 1;
 // have been submitted by then.  Nothing observable changes (submit_pending runs before every use of the
 // stream).  Round 1 handed over in fixed batches of four behind one wait packet: 35.2 us/frame where this
 // gives 34.2 (same box), and at small frames 25 -> 20.5 us (800^2), 24.8 -> 22.4 (2048^2).
-constexpr int BATCH = LOOKAHEAD - 1;
+constexpr int BATCH = LOOKAHEAD - 1;  // passes that may be pending (setup queued, tile kernel not yet)
 constexpr int RING = 16;  // events: pass p's are waited for until pass p + LOOKAHEAD is set up
 
 struct tr_scene {
