@@ -153,7 +153,8 @@ int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row
  * with concurrent DMA-engine copies over xGMI, after the work queued on `stream` so far, and makes
  * `stream` wait until every peer's range has arrived in the local slot.  Collective: every rank calls it
  * for the same slots in the same order.  Failures of a peer surface as TR_E_EXCHANGE from
- * tr_exchange_status / tr_exchange_read after a ten-second device-side timeout, never as a hang. */
+ * tr_exchange_status / tr_exchange_read after a device-side timeout (ten seconds; the environment
+ * variable TR_EXCHANGE_TIMEOUT_MS, read at create, overrides it), never as a hang. */
 #define TR_EXCHANGE_HANDLE_BYTES 256
 typedef struct tr_exchange tr_exchange;
 int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, tr_exchange **out);

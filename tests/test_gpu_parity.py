@@ -692,3 +692,54 @@ def test_peer_exchange_two_processes_one_gpu(diablo):
     assert j["n_gpus"] == 2 and j["group_ranks"] == 2 and j["parity_vs_oracle"]["ok"]
     assert "peer-to-peer" in j["config"]["sharding"] and len(j["per_rank"]) == 2
     assert j["per_rank"][0]["band_rows"] == [0, 512] and j["per_rank"][1]["band_rows"] == [512, 1024]
+
+
+def _exchange_rank(rank, q_in, q_out, participate):
+    import ctypes as C
+    import os
+    os.environ["TR_EXCHANGE_TIMEOUT_MS"] = "1500"
+    import tiny_renderer_amd as T
+    from tiny_renderer_amd._lib import TR_EXCHANGE_HANDLE_BYTES
+    L = T.load_library()
+    h = C.c_void_p()
+    n = 1 << 20
+    assert L.tr_exchange_create(0, 2, rank, 1, n, C.byref(h)) == 0
+    rec = C.create_string_buffer(TR_EXCHANGE_HANDLE_BYTES)
+    assert L.tr_exchange_export(h, rec) == 0
+    q_out.put((rank, bytes(rec.raw)))
+    records = q_in.get(timeout=120)
+    assert L.tr_exchange_connect(h, b"".join(records)) == 0
+    code = 0
+    if participate:
+        assert L.tr_exchange_all_gather(h, 0, rank * (n // 2), n // 2, None) == 0
+        out = (C.c_uint8 * n)()
+        code = L.tr_exchange_read(h, 0, out, n)
+    q_out.put(("done", rank, code))
+    q_in.get(timeout=120)   # stay alive (mappings valid) until told to leave
+    L.tr_exchange_destroy(h)
+
+
+def test_peer_exchange_reports_a_missing_rank(built):
+    """A rank whose peer never joins the all-gather must not hang the GPU: the device-side waits give up
+    (TR_EXCHANGE_TIMEOUT_MS = 1.5 s here, ten seconds by default) and the status is TR_E_EXCHANGE."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    q_ins = [ctx.Queue(), ctx.Queue()]
+    procs = [ctx.Process(target=_exchange_rank, args=(r, q_ins[r], q_out, r == 0)) for r in range(2)]
+    for p in procs:
+        p.start()
+    recs = dict(q_out.get(timeout=180) for _ in range(2))
+    for q in q_ins:
+        q.put([recs[0], recs[1]])
+    done = {}
+    for _ in range(2):
+        tag, rank, code = q_out.get(timeout=180)
+        done[rank] = code
+    for q in q_ins:
+        q.put("leave")
+    for p in procs:
+        p.join(60)
+    assert done[0] == -11, done    # TR_E_EXCHANGE on the rank that waited alone
+    assert done[1] == 0
+    assert all(p.exitcode == 0 for p in procs)

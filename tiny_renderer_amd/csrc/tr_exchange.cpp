@@ -23,6 +23,7 @@
 // (tests/test_gpu_parity.py::test_peer_exchange_two_processes_one_gpu) -- cross-GPU runs are the
 // driver's (8-GPU node).
 #include <hip/hip_runtime_api.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -76,6 +77,7 @@ struct tr_exchange {
     uint32_t **d_wait_list = nullptr;  // device array of flag pointers for the arrival wait: [slot][peer]
     uint32_t **d_open_list = nullptr;  // ... and of the peers' "open" flags this rank stores into: [slot][peer]
     bool connected = false;
+    uint64_t timeout_ticks = 1000000000ull;  // 10 s of the 100 MHz wall clock; TR_EXCHANGE_TIMEOUT_MS overrides (tests)
 };
 
 extern "C" {
@@ -94,6 +96,10 @@ int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_s
     x->rank = rank;
     x->n_slots = n_slots;
     x->frame_bytes = frame_bytes;
+    if (const char *ms = getenv("TR_EXCHANGE_TIMEOUT_MS")) {
+        const long v = atol(ms);
+        if (v > 0) x->timeout_ticks = (uint64_t)v * 100000ull;
+    }
     hipError_t e = hipSuccess;
     for (uint32_t b = 0; b < n_slots && e == hipSuccess; b++) {
         e = hipMalloc((void **)&x->frame[b], frame_bytes);
@@ -193,7 +199,7 @@ int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t 
         if (p == r) continue;
         hipStream_t c = x->copy_stream[p];
         HIP_TRY(hipStreamWaitEvent(c, x->fork, 0));
-        int rc = tr::launch_flag_wait(x->flags + FlagIndex::open(slot, p), g, x->flags + FlagIndex::error(), c);
+        int rc = tr::launch_flag_wait(x->flags + FlagIndex::open(slot, p), g, x->flags + FlagIndex::error(), x->timeout_ticks, c);
         if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
         if (bytes)
             HIP_TRY(hipMemcpyAsync(x->peer_frame[slot][p] + offset, x->frame[slot] + offset, bytes, hipMemcpyDeviceToDevice, c));
@@ -206,7 +212,7 @@ int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t 
         if (p != r) HIP_TRY(hipStreamWaitEvent(stream, x->copy_done[p], 0));
     if (x->n_ranks > 1) {
         int rc = tr::launch_flags_wait_all(x->d_wait_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g,
-                                           x->flags + FlagIndex::error(), stream);
+                                           x->flags + FlagIndex::error(), x->timeout_ticks, stream);
         if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
     }
     return TR_OK;
@@ -218,7 +224,7 @@ int tr_exchange_status(tr_exchange *x)
     HIP_TRY(hipSetDevice(x->device));
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, x->flags + FlagIndex::error(), 4, hipMemcpyDeviceToHost));
-    if (err) return tr::fail(TR_E_EXCHANGE, "a peer's band did not arrive within ten seconds (the rank is gone or out of step)");
+    if (err) return tr::fail(TR_E_EXCHANGE, "a peer's band did not arrive in time (the rank is gone or out of step)");
     return TR_OK;
 }
 

@@ -26,11 +26,12 @@ int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &fram
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
                     uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st);
 // Peer exchange flags (tr_exchange.cpp): system-scope store of a generation number; waits that poll
-// until flag >= value (as a wrapping distance) and raise *error after ten seconds
+// until flag >= value (as a wrapping distance) and raise *error after timeout_ticks of the 100 MHz wall clock
 int launch_flag_store(uint32_t *flag, uint32_t value, hipStream_t st);
 int launch_flags_store_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, hipStream_t st);
-int launch_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, hipStream_t st);
-int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, uint32_t *error, hipStream_t st);
+int launch_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, uint64_t timeout_ticks, hipStream_t st);
+int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, uint32_t *error,
+                          uint64_t timeout_ticks, hipStream_t st);
 // rcp2 (which = 0) / sqrt2 (1) of tr_pk.h against '/' and sqrtf for the f32 bit patterns [first, first + count)
 int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned long long *n_bad, uint32_t *bad_bits,
                           hipStream_t st);

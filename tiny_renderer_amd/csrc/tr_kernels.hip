@@ -997,8 +997,9 @@ __global__ __launch_bounds__(256) void k_selftest_unary(int which, uint32_t firs
 
 // -----------------------------------------------------------------------------------------
 // Peer exchange flags (tr_exchange.cpp): generation counters in uncached memory, possibly another
-// GPU's.  Stores and loads are system scope; a waiter sleeps between polls and gives up after about
-// ten seconds of the 100 MHz wall clock, raising the error word instead of hanging the queue.
+// GPU's.  Stores and loads are system scope; a waiter sleeps between polls and gives up after
+// `timeout_ticks` of the 100 MHz wall clock (ten seconds unless the host says otherwise), raising the
+// error word instead of hanging the queue.
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_flag_store(uint32_t *flag, uint32_t value)
 {
@@ -1017,13 +1018,13 @@ __global__ __launch_bounds__(64) void k_flags_store_all(uint32_t *const *flags, 
     }
 }
 
-__device__ __forceinline__ void spin_until_at_least(uint32_t *flag, uint32_t value, uint32_t *error)
+__device__ __forceinline__ void spin_until_at_least(uint32_t *flag, uint32_t value, uint32_t *error, uint64_t timeout_ticks)
 {
     const uint64_t t0 = wall_clock64();
     // generations are compared as a signed distance so that the counter may wrap
     while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > 1000000000ull) {  // 10 s
+        if (wall_clock64() - t0 > timeout_ticks) {
             __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
@@ -1031,15 +1032,15 @@ __device__ __forceinline__ void spin_until_at_least(uint32_t *flag, uint32_t val
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
-__global__ __launch_bounds__(64) void k_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error)
+__global__ __launch_bounds__(64) void k_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, uint64_t timeout_ticks)
 {
-    if (threadIdx.x == 0u) spin_until_at_least(flag, value, error);
+    if (threadIdx.x == 0u) spin_until_at_least(flag, value, error, timeout_ticks);
 }
 
 __global__ __launch_bounds__(64) void k_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value,
-                                                       uint32_t *error)
+                                                       uint32_t *error, uint64_t timeout_ticks)
 {
-    if (threadIdx.x < n && threadIdx.x != skip) spin_until_at_least(flags[threadIdx.x], value, error);
+    if (threadIdx.x < n && threadIdx.x != skip) spin_until_at_least(flags[threadIdx.x], value, error, timeout_ticks);
 }
 
 }  // namespace
@@ -1059,17 +1060,18 @@ int launch_flags_store_all(uint32_t *const *flags, uint32_t n, uint32_t skip, ui
     return e_ == hipSuccess ? 0 : (int)e_;
 }
 
-int launch_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, hipStream_t st)
+int launch_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, uint64_t timeout_ticks, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, st, flag, value, error);
+    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, st, flag, value, error, timeout_ticks);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }
 
-int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, uint32_t *error, hipStream_t st)
+int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, uint32_t *error,
+                          uint64_t timeout_ticks, hipStream_t st)
 {
     if (n > 64u) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_flags_wait_all, dim3(1), dim3(64), 0, st, flags, n, skip, value, error);
+    hipLaunchKernelGGL(k_flags_wait_all, dim3(1), dim3(64), 0, st, flags, n, skip, value, error, timeout_ticks);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }
