@@ -339,7 +339,7 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 #define TR_WPE_DARBOUX 4
 #endif
 #ifndef TR_WPE_NORMAL_MAP
-#define TR_WPE_NORMAL_MAP 5
+#define TR_WPE_NORMAL_MAP 6
 #endif
 constexpr int tile_waves_per_eu(int fs, int tile_waves)
 {
@@ -714,10 +714,19 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // The loop exists twice: for bins that stay resident in LDS (nearly all) and for the rare larger
     // ones, whose survivors' records come from global memory -- a run-time choice inside the loop
     // cost a dozen register moves per step where the two paths merge.
-    auto shade_steps = [&](auto in_lds) {
+    // ... and in two flavours of the closure call: PAIR runs the two-pixel closures (tr_shaders.h) and
+    // returns the steps in which a surviving pixel left their guarded range; those steps are then run
+    // again, whole, with the plain closures (every store of a step is repeated, so the second run
+    // simply overwrites the first).  Keeping the plain closures out of the fast loop's body matters:
+    // inline, as the fallback of each step, their registers were live across the fast path and cost
+    // 5-9 % (spills) although they almost never ran.
+    auto shade_steps = [&](auto in_lds, auto pair_tag, uint32_t step_mask) -> uint32_t {
     constexpr bool RESIDENT = decltype(in_lds)::value;
+    constexpr bool PAIR = decltype(pair_tag)::value;
+    uint32_t redo = 0u;
 #pragma unroll 1
     for (int32_t sstep = 0; sstep < NSTEP; sstep++) {
+        if (!((step_mask >> sstep) & 1u)) continue;
         int32_t row[2], py[2];
         bool live[2], won[2];
         uint32_t wslot[2];
@@ -810,12 +819,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                         return fragment_color<FS>(a.u, a.tex, v, b, u_, v_, (uint32_t)px, (uint32_t)py_, z_, a.shadow,
                                                   (uint32_t)W, (uint32_t)H, e_);
                     };
-                    bool plain = true;
-                    if (has_pair_closure(FS)) {
+                    if (PAIR) {
                         // both pixels through the closure together in packed arithmetic with shared
-                        // reciprocals (tr_shaders.h, fragment_color_pair); a pixel whose operands leave the
-                        // range that form is proven on takes the plain closure below (rare: exact zeros
-                        // among the normalised components, or a degenerate basis)
+                        // reciprocals (tr_shaders.h, fragment_color_pair); a step in which a surviving pixel's
+                        // operands leave the range that form is proven on is run again with the plain
+                        // closure (rare: exact zeros among the normalised components, a degenerate basis)
                         auto vary2 = [&](int k) -> f2 {
                             const int i = k < 2 ? 3 : (k + 14) / 4, c = k < 2 ? k + 2 : (k + 14) % 4;
                             const uint4 pa = i < TOP ? qa[i] : ra[i], pb = i < TOP ? qb[i] : rb[i];
@@ -824,17 +832,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
                             return mk2(__uint_as_float(wa), __uint_as_float(wb));
                         };
                         bool bad_a, bad_b;
-                        uint32_t fa = 0u, fb_ = 0u;
                         vec3p barp;
                         barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
-                        fragment_color_pair<FS>(a.u, a.tex, vary2, barp, uu, vv, ca, cb, fa, fb_, bad_a, bad_b);
-                        plain = __any((bad_a && won[0]) || (bad_b && won[1]));
-                        if (!plain) {
-                            ea = fa;
-                            eb = fb_;
+                        fragment_color_pair<FS>(a.u, a.tex, vary2, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
+                        if (__any((bad_a && won[0]) || (bad_b && won[1]))) {
+                            redo |= 1u << sstep;
+                            ea = eb = 0u;  // the second run reports this step's lookups
                         }
-                    }
-                    if (plain) {
+                    } else {
                         ca = closure(qa, ra, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, py[0], z.x, ea);
                         __builtin_amdgcn_sched_barrier(0);
                         cb = closure(qb, rb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, py[1], z.y, eb);
@@ -892,11 +897,21 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    return redo;
     };
+    constexpr uint32_t ALL_STEPS = (1u << NSTEP) - 1u;
+    constexpr bool HAS_PAIR = has_pair_closure(FS);
+    uint32_t redo;
     if (resident)
-        shade_steps(std::true_type{});
+        redo = shade_steps(std::true_type{}, std::bool_constant<HAS_PAIR>{}, ALL_STEPS);
     else
-        shade_steps(std::false_type{});
+        redo = shade_steps(std::false_type{}, std::bool_constant<HAS_PAIR>{}, ALL_STEPS);
+    if (HAS_PAIR && redo != 0u) {
+        if (resident)
+            shade_steps(std::true_type{}, std::false_type{}, redo);
+        else
+            shade_steps(std::false_type{}, std::false_type{}, redo);
+    }
 
     if (a.zclean && tid == 0u) a.zclean[tile] = 0u;
     if (!DEPTH && a.fbclean && tid == 0u) a.fbclean[tile] = 0u;
