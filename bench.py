@@ -3,10 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame through the reference's per-frame protocol (app.rs:170,208-213):
+A "step" is one frame of the reference's per-frame protocol (app.rs:170,208-213):
 clear -> set_light_direction -> set_camera -> render, with the finished frame left in HBM
 (`get_frame_buffer`'s vertical flip is folded into the render's store address; no host
 readback inside the timed region; the readback-inclusive rate is reported beside it).
+At N=1 the K steps are submitted through tr_scene_render_frames (the library's throughput path: the
+same K frames, each into render targets of its own, but `config.frames_per_launch` of them rendered
+by one launch of each kernel); `--submit frame` issues the four calls per frame instead, and the
+default run reports that rate too (`per_frame_protocol`).
 
 Workload at N=1: diablo.obj, -s phong, 4096x4096 -- the configuration the metric
 "Mpixels/s shaded (z-test + Phong) at 4096x4096" is quoted on.  `value` =
@@ -123,6 +127,9 @@ def main():
                     help="N>1: how the bands travel: torch.distributed all_gather (RCCL) or the library's "
                          "peer-to-peer band copies (tr_exchange_*)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the render stream (no double buffering)")
+    ap.add_argument("--submit", choices=("frames", "frame"), default="frames",
+                    help="N=1: frames = tr_scene_render_frames (groups of frames per launch), frame = four calls per frame")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="tr_options.frames_per_launch (0 = automatic)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -208,13 +215,18 @@ def main():
         exchange = T.PeerExchange(n_buf, H * W * 3, rank, world, device_index)
         fbs = None
         fb_ptr = [exchange.frame_ptr(b) for b in range(n_buf)]
-    else:
+    elif use_dist:
         fbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
         fb_ptr = [fb.data_ptr() for fb in fbs]
+    else:
+        fbs, fb_ptr = None, [None]  # N = 1: the scene's own frame slots
     torch.cuda.synchronize()
+    grouped = (not use_dist) and args.submit == "frames"
     scene = T.Scene(W, H, mesh, texs, pipe, device=device_index,
                     stream=render_stream.cuda_stream if use_dist else None,
-                    frame_buffer_device=fb_ptr[0], band_rows=band)
+                    frame_buffer_device=fb_ptr[0] if use_dist else None, band_rows=band,
+                    frames_per_launch=args.frames_per_launch)
+    frames_per_launch = scene.frames_per_launch if grouped else 1
     chunks = None
     band_bytes = 0
     if use_dist:
@@ -223,6 +235,8 @@ def main():
             chunks = [fb[rank * band_bytes:(rank + 1) * band_bytes] for fb in fbs]
 
     def read_frame(b):
+        if not use_dist:
+            return scene.get_frame_buffer()
         if exchange is not None:
             return exchange.read(b, H, W)
         return fbs[b].cpu().numpy().reshape(H, W, 3)
@@ -275,6 +289,23 @@ def main():
             gathered[b].record(comm_stream)
         timing["timed"][b] = timing["on"]
 
+    def frame_params(cams):
+        out = np.zeros((len(cams), 12), np.float32)
+        out[:, 0:3] = lt
+        for i, c in enumerate(cams):
+            out[i, 3:6], out[i, 6:9], out[i, 9:12] = c
+        return out
+
+    headline_params = frame_params([cam] * max(args.steps, args.warmup, 1))
+
+    def run(k, cams=None, per_frame=False):
+        """k steps.  Grouped submission: ONE tr_scene_render_frames call for all of them."""
+        if grouped and not per_frame:
+            scene.render_frames(headline_params[:k] if cams is None else frame_params(cams))
+            return
+        for i in range(k):
+            step(cam if cams is None else cams[i])
+
     def barrier():
         if use_dist:
             dist.barrier()
@@ -299,8 +330,7 @@ def main():
         return (not any_rank(overflow)), st
 
     for attempt in range(4):   # warm-up; again if it is what made the bins grow
-        for _ in range(args.warmup):
-            step()
+        run(args.warmup)
         device_idle()
         ok, _ = clean_sync()
         if ok:
@@ -308,8 +338,7 @@ def main():
     barrier()
     device_idle()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     device_idle()
     barrier()
     device_idle()
@@ -328,21 +357,31 @@ def main():
     # (deterministic stand-in for the reference's keyboard orbit, app.rs:173-200); not `value`.
     orbit_frames, orbit_elapsed, orbit_status = 200, None, None
     if extras:
+        orbit_cams = [camera(2.0 * np.pi * i / orbit_frames) for i in range(orbit_frames)]
         for lap in range(4):   # warm-up laps: the bins grow to what every angle needs (a frame whose bins
-            for i in range(orbit_frames):   # overflowed on a caller's stream is reported, not silently repaired)
-                step(camera(2.0 * np.pi * i / orbit_frames))
+            run(orbit_frames, orbit_cams)   # overflowed on a caller's stream is reported, not silently repaired)
             device_idle()
             ok, _ = clean_sync()
             if ok:
                 break
         barrier()
         t1 = time.perf_counter()
-        for i in range(orbit_frames):
-            step(camera(2.0 * np.pi * i / orbit_frames))
+        run(orbit_frames, orbit_cams)
         device_idle()
         barrier()
         orbit_elapsed = time.perf_counter() - t1
         ok, orbit_status = clean_sync()
+
+    # ---- the same steps through the reference's own per-frame protocol (four calls per frame) ---------
+    per_frame_elapsed, per_frame_steps = None, min(args.steps, 500)
+    if extras and grouped:
+        run(50, per_frame=True)
+        device_idle()
+        t1 = time.perf_counter()
+        run(per_frame_steps, per_frame=True)
+        device_idle()
+        per_frame_elapsed = time.perf_counter() - t1
+        scene.sync()
 
     # ---- single-frame latency: clear -> render -> sync with nothing else in flight -----------------
     latency_us = None
@@ -376,15 +415,11 @@ def main():
         scene.sync()
         readback = (time.perf_counter() - t1) / n_rb
 
-    step()  # back to the headline frame for the parity check below
-    device_idle()
-    last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
-
-    # ---- per-kernel device time of the same step, HIP events on the kernels' own dispatches ----------
+    # ---- per-kernel device time of the same steps, HIP events on the kernels' own dispatches ----------
+    # (ends on the headline frame: the parity check below reads it)
     scene.profile_enable(True)
     timing["on"] = use_dist
-    for _ in range(min(args.steps, 400) if use_dist else args.steps):
-        step()
+    run(min(args.steps, 400) if use_dist else args.steps)
     device_idle()
     timing["on"] = False
     for b in range(n_buf if use_dist else 0):
@@ -399,7 +434,7 @@ def main():
         mine = {"rank": rank, "band_rows": list(band),
                 "render_us": round(float(np.median(timing["render_ms"])) * 1e3, 2) if timing["render_ms"] else None,
                 "gather_us": round(float(np.median(timing["gather_ms"])) * 1e3, 2) if timing["gather_ms"] else None,
-                "k_tile_us": round(prof["k_tile"]["total_ms"] / max(prof["k_tile"]["launches"], 1) * 1e3, 2)
+                "k_tile_us": round(prof["k_tile"]["total_ms"] / max(prof["k_tile"]["frames"], 1) * 1e3, 2)
                 if "k_tile" in prof else None}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -461,8 +496,11 @@ def main():
         roofline = None
         if tile and tile["launches"]:
             avg_s = tile["total_ms"] / tile["launches"] / 1e3
-            # one launch = one pass over the frame (or over this rank's band of it)
-            ach = bytes_alg / world / avg_s / 1e9
+            # one launch = one pass over the frames of a group (N=1: frames_per_launch of them; the profiled
+            # loop's launches / frames are counted by the library) or over this rank's band of one frame
+            frames_in_launch = tile["frames"] / tile["launches"]
+            bytes_launch = bytes_alg * frames_in_launch / world
+            ach = bytes_launch / avg_s / 1e9
             traffic, traffic_note = None, "not profiled"
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
@@ -478,6 +516,8 @@ def main():
                         traffic_note = "workload not profiled"
                     elif db.get("source_fingerprint") != source_fingerprint():
                         traffic_note = "profiles/pmc_traffic.json was collected on other source (%s)" % db.get("source_fingerprint")
+                    elif abs(entry.get("frames_per_launch", 1) - frames_in_launch) > 0.05 * frames_in_launch:
+                        traffic_note = "profiled with %s frames per launch" % entry.get("frames_per_launch", 1)
                     elif entry.get("kernel") == dom:
                         traffic = entry.get("hbm_bytes_per_launch")
                         traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
@@ -491,7 +531,9 @@ def main():
                         "physical_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                         "limiter": "vector/scalar instruction issue of the tiles with polygons, not HBM "
                                    "(SQ counters under profiles/)",
-                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_alg // world,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "frames_per_launch": round(frames_in_launch, 3),
+                        "avg_launch_us_per_frame": round(avg_s * 1e6 / frames_in_launch, 2),
+                        "algorithmic_bytes_per_launch": int(bytes_launch),
                         "algorithmic_bytes_per_frame": sum(bytes_by_kernel.values())}
         ms = elapsed / args.steps * 1e3
         t_frame = None
@@ -514,6 +556,10 @@ def main():
             "data": data,
             "config": {"workload": workload, "n_shaded_per_frame": n_shaded,
                        "polygons": int(mesh["idx"].shape[0]),
+                       "submission": ("tr_scene_render_frames: %d frames per launch of each kernel, every frame into "
+                                      "render targets of its own" % frames_per_launch) if grouped
+                       else "per frame: clear, set_light_direction, set_camera, render",
+                       "frames_per_launch": frames_per_launch,
                        "sharding": ("screen row bands (tr_band_rows) + %s of the framebuffer%s" % (
                            "RCCL all-gather" if exchange is None else "peer-to-peer band copies (tr_exchange)",
                            "" if args.no_overlap else ", double-buffered: exchange of frame f under the render of f+1"))
@@ -522,6 +568,11 @@ def main():
             "frames_per_s": round(args.steps / elapsed, 1),
             "frames_per_s_orbit": round(orbit_frames / orbit_elapsed, 1) if orbit_elapsed and orbit_status == 0 else None,
             "framebuffer_mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
+            "per_frame_protocol": {"ms_per_step": round(per_frame_elapsed / per_frame_steps * 1e3, 5),
+                                   "value": round(n_shaded * per_frame_steps / per_frame_elapsed / 1e6, 2),
+                                   "steps": per_frame_steps,
+                                   "what": "the same frames through clear / set_light_direction / set_camera / render, "
+                                           "one launch of each kernel per frame"} if per_frame_elapsed else None,
             "t_frame_us": t_frame,
             "latency_us": latency_us,
             "readback_inclusive_mpixels_per_s": round(n_shaded / readback / 1e6, 1) if readback else None,
@@ -529,6 +580,7 @@ def main():
             "parity_vs_oracle": {"ok": parity_ok, "max_abs_rgb_diff": int(diff.max()), "tolerance": tol},
             "device_status": status,
             "kernel_us": {k: round(v["total_ms"] / max(v["launches"], 1) * 1e3, 2) for k, v in prof.items()},
+            "kernel_us_per_frame": {k: round(v["total_ms"] / max(v["frames"], 1) * 1e3, 2) for k, v in prof.items()},
             "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 1
+#define TR_ABI_VERSION 2
 
 /* Status codes.  0 = ok, negative = failure (the reference panics at the cited site). */
 enum {
@@ -84,6 +84,8 @@ typedef struct tr_options {
                                   sees every polygon of the bin, 2 = each owns a share of the bin and sees the
                                   whole tile (depth resolve through LDS atomics), 0 = automatic.
                                   Speed only: results do not depend on it. */
+    uint32_t frames_per_launch; /* tr_scene_render_frames: frames rendered by one launch of each kernel (1..16), 0 =
+                                  automatic (by tile count: 4 at 4096x4096, 16 for small frames).  Speed only. */
 } tr_options;
 
 typedef struct tr_scene tr_scene;
@@ -102,6 +104,32 @@ int tr_scene_set_light_direction(tr_scene *s, const float v[3]); /* scene.rs:140
 int tr_scene_set_camera(tr_scene *s, const float look_from[3], const float look_at[3],
                         const float up[3]);                       /* scene.rs:145-149 */
 int tr_scene_render(tr_scene *s);                                 /* scene.rs:151-268 (async) */
+
+/* Many frames per call -- the throughput path (nothing of the kind upstream, whose caller renders one frame per
+ * window refresh, app.rs:170-213).  Frame i of the call is exactly what
+ *     tr_scene_clear; tr_scene_set_light_direction(frames[i].light);
+ *     tr_scene_set_camera(frames[i].look_from, .look_at, .up); tr_scene_render
+ * produces, but the frames of a group (tr_scene_frames_per_launch of them) are rendered TOGETHER, by one launch of
+ * each kernel: a lone frame leaves the GPU draining for a third of its tile kernel at 4096x4096, and a small frame
+ * never fills it.  Each frame of a group has render targets of its own ("frame slots": z, colour, shadow buffer);
+ * frame i uses slot i % frames_per_launch, so when the call returns its LAST frames_per_launch frames exist
+ * (tr_scene_frames_kept).  The scene is left as the per-frame calls would leave it: light and camera of the last
+ * frame, the last frame current for every getter and for a later tr_scene_render without clear.
+ * frame_buffers_device: NULL (colour into the slots' own buffers) or n_frames device pointers of 3*W*H bytes each,
+ * frame i's colour target (e.g. the all-gather buffers of a multi-GPU caller); a buffer belongs to the scene as in
+ * tr_scene_set_frame_buffer_device.  Asynchronous like tr_scene_render: on a caller's stream all the frames'
+ * kernels are enqueued when the call returns. */
+typedef struct tr_frame_params {
+    float light[3];
+    float look_from[3], look_at[3], up[3];
+} tr_frame_params;
+int tr_scene_render_frames(tr_scene *s, uint32_t n_frames, const tr_frame_params *frames, void *const *frame_buffers_device);
+int tr_scene_frames_per_launch(tr_scene *s); /* frames per group of this scene */
+int tr_scene_frames_kept(tr_scene *s);       /* frames of the last tr_scene_render_frames call that still exist
+                                                (0 after a tr_scene_render) */
+/* Makes the frame `back` frames before the last one of that call (0 = the last) the scene's current frame: getters,
+ * tr_scene_frame_buffer_device and later renders refer to its targets, light and camera. */
+int tr_scene_select_frame(tr_scene *s, uint32_t back);
 
 /* scene.rs:92-125.  Caller-owned host buffers of 3*W*H bytes, row 0 = top.  Synchronizes.
  * Returns the sticky device status (TR_E_OOB_LOOKUP, TR_E_BIN_OVERFLOW) of the frame. */
@@ -176,6 +204,7 @@ typedef struct tr_kernel_time {
     char name[32];
     uint64_t launches;
     double total_ms;
+    uint64_t frames; /* frames those launches covered (= launches, except for tr_scene_render_frames' fused launches) */
 } tr_kernel_time;
 int tr_scene_profile_enable(tr_scene *s, int on);
 /* Fills up to `cap` entries, returns the number of kernels or a negative status. */

@@ -1,0 +1,259 @@
+"""Frame groups (tr_scene_render_frames): several cleared frames rendered by ONE launch of each kernel,
+every frame into render targets of its own.  Frame i of a call must be bit for bit what the reference's
+per-frame protocol (clear -> set_light_direction -> set_camera -> render, app.rs:170-213) gives -- i.e.
+what the CPU oracle renders for that light and camera -- whatever the group size, the position of the
+frame in its group, the tile layout, or what the scene did before and does afterwards.
+PARITY UNPINNED upstream: the oracle is the normative restatement (oracle/tr_oracle.h)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+EXACT = ("default", "phong", "normal_map", "darboux", "shadow", "occlusion")
+ALL = EXACT + ("specular",)
+
+
+def specular_exact():
+    import tiny_renderer_amd as T
+    return bool(T.load_library().tr_specular_exact())
+
+
+def params(n, cam0=0.0, cam_step=0.37, light0=-0.5, light_step=0.23):
+    """[n, 12]: light, look_from, look_at, up per frame -- every frame differs from its neighbours."""
+    out = np.zeros((n, 12), np.float32)
+    for i in range(n):
+        out[i, 0:3] = H.light(light0 + light_step * i)
+        f, a, u = H.camera(cam0 + cam_step * i)
+        out[i, 3:6], out[i, 6:9], out[i, 9:12] = f, a, u
+    return out
+
+
+def oracle_frames(W, Hh, mesh, texs, pipe, p, band=None):
+    from oracle import oracle as O
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    if band is not None:
+        cpu.set_output_band(*band)
+    out = []
+    for q in p:
+        cpu.clear()
+        cpu.set_light_direction(q[0:3])
+        cpu.set_camera(q[3:6], q[6:9], q[9:12])
+        assert cpu.render() == 0
+        out.append((cpu.get_frame_buffer().copy(), cpu.z_f32().view(np.uint32).copy(),
+                    cpu.shadow_f32().view(np.uint32).copy() if pipe in ("shadow", "occlusion") else None))
+    return out
+
+
+def check_kept(gpu, expect, pipe, n):
+    """Every frame the call left behind, newest first, against the oracle's frames."""
+    kept = gpu.frames_kept()
+    assert kept == min(n, gpu.frames_per_launch)
+    for back in range(kept):
+        gpu.select_frame(back)
+        fo, zo, so = expect[n - 1 - back]
+        zg = gpu.read_z_f32().view(np.uint32)
+        assert np.array_equal(zg, zo), "frame -%d: z bits differ at %d pixels" % (back, int((zg != zo).sum()))
+        if so is not None:
+            sg = gpu.read_shadow_f32().view(np.uint32)
+            assert np.array_equal(sg, so), "frame -%d: shadow bits differ at %d pixels" % (back, int((sg != so).sum()))
+        fg = gpu.get_frame_buffer()
+        if pipe in EXACT or specular_exact():
+            assert np.array_equal(fg, fo), "frame -%d: rgb differs at %d pixels" % (back, int((fg != fo).any(-1).sum()))
+        else:
+            assert np.abs(fg.astype(np.int32) - fo.astype(np.int32)).max() <= 1  # tolerance: 1 LSB (device powf)
+        assert fo.any(), "an empty frame proves nothing"
+    gpu.select_frame(0)
+
+
+@pytest.mark.parametrize("pipe", ALL)
+def test_group_frames_match_the_oracle(synthetic, pipe):
+    import tiny_renderer_amd as T
+    mesh, texs = synthetic
+    W, Hh, n = 640, 480, 7
+    p = params(n)
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, frames_per_launch=4)   # groups of 4 + 3
+    assert gpu.frames_per_launch == 4
+    gpu.render_frames(p)
+    assert gpu.sync() == 0
+    check_kept(gpu, oracle_frames(W, Hh, mesh, texs, pipe, p), pipe, n)
+    gpu.close()
+
+
+@pytest.mark.parametrize("fpl", [1, 2, 3, 8, 16, 0])
+@pytest.mark.parametrize("n", [1, 5, 16, 19])
+def test_group_sizes_and_counts(small_synthetic, fpl, n):
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W, Hh = 520, 300
+    p = params(n, cam_step=0.21)
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", frames_per_launch=fpl)
+    gpu.render_frames(p)
+    check_kept(gpu, oracle_frames(W, Hh, mesh, texs, "phong", p), "phong", n)
+    gpu.close()
+
+
+@pytest.mark.parametrize("pipe", ["phong", "darboux", "shadow"])
+@pytest.mark.parametrize("waves", [4, 8, 16])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_group_tile_layouts(small_synthetic, pipe, waves, mode):
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W, Hh, n = 400, 200, 5
+    p = params(n)
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, tile_waves=waves, tile_mode=mode, frames_per_launch=4)
+    gpu.render_frames(p)
+    check_kept(gpu, oracle_frames(W, Hh, mesh, texs, pipe, p), pipe, n)
+    gpu.close()
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow"])
+def test_groups_between_per_frame_renders(small_synthetic, pipe):
+    """Per-frame renders before a group call, an accumulating render and a cleared one after it, a second
+    group call after those: the per-frame path and the groups share streams, bins' capacity and targets."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 384, 256
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, frames_per_launch=4)
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+
+    def both(fn):
+        fn(gpu), fn(cpu)
+
+    def same():
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
+        assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer())
+
+    for f in range(3):  # frames in flight on the per-frame path when the group call arrives
+        both(lambda s: (s.clear(), s.set_light_direction(H.light(0.1 * f)), s.set_camera(*H.camera(0.5 * f)), s.render()))
+    p = params(6, cam0=1.0)
+    gpu.render_frames(p)
+    expect = oracle_frames(W, Hh, mesh, texs, pipe, p)
+    check_kept(gpu, expect, pipe, 6)
+    # the oracle scene follows: its state after the call is the last frame's
+    cpu.clear(), cpu.set_light_direction(p[-1, 0:3]), cpu.set_camera(p[-1, 3:6], p[-1, 6:9], p[-1, 9:12]), cpu.render()
+    same()
+    # accumulate into the last frame (no clear): light and camera are the last frame's unless set again
+    both(lambda s: (s.set_camera(*H.camera(2.2)), s.render()))
+    same()
+    both(lambda s: (s.clear(), s.set_light_direction(H.light(0.9)), s.render()))
+    same()
+    # an older frame of the call, selected and accumulated into
+    p2 = params(4, cam0=-1.0, cam_step=0.5)
+    gpu.render_frames(p2)
+    gpu.select_frame(2)
+    cpu.clear(), cpu.set_light_direction(p2[1, 0:3]), cpu.set_camera(p2[1, 3:6], p2[1, 6:9], p2[1, 9:12]), cpu.render()
+    same()
+    both(lambda s: (s.set_camera(*H.camera(0.3)), s.render()))
+    same()
+    assert gpu.frames_kept() == 0  # a per-frame render ends the call's selection
+    with pytest.raises(T.TinyRendererError):
+        gpu.select_frame(0)
+    gpu.close()
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow"])
+def test_group_bin_overflow_renders_the_kept_frames_again(synthetic, pipe):
+    """Bins too small for the frames of a group: found at the first getter, the bins grow and the frames
+    the call left behind are rendered again -- every one of them, not only the last."""
+    import tiny_renderer_amd as T
+    mesh, texs = synthetic  # 5 022 polygons on a 256x256 frame: hundreds per tile
+    W, Hh, n = 256, 256, 6
+    p = params(n)
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, bin_capacity=64, frames_per_launch=4)
+    gpu.render_frames(p)
+    expect = oracle_frames(W, Hh, mesh, texs, pipe, p)
+    check_kept(gpu, expect, pipe, n)
+    # the grown bins serve the next call directly
+    p2 = params(3, cam0=2.0)
+    gpu.render_frames(p2)
+    assert gpu.sync() == 0
+    check_kept(gpu, oracle_frames(W, Hh, mesh, texs, pipe, p2), pipe, 3)
+    gpu.close()
+
+
+def test_group_on_a_callers_stream_into_callers_buffers(small_synthetic):
+    """The multi-GPU pattern: a caller's stream, the caller's frame tensors as colour targets, the frames
+    consumed on that stream without host synchronisation; a band scene writes its rows only."""
+    import torch
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W, Hh, n = 768, 512, 10
+    band = (128, 384)
+    side = torch.cuda.Stream()
+    bufs = [torch.full((Hh * W * 3,), 77, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    kept = torch.zeros(n, Hh * W * 3, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", stream=side.cuda_stream, frame_buffer_device=bufs[0].data_ptr(),
+                  band_rows=band, frames_per_launch=4)
+    p = params(n)
+    with torch.cuda.stream(side):
+        for i0 in range(0, n, 4):
+            g = min(4, n - i0)
+            gpu.render_frames(p[i0:i0 + g], [bufs[j].data_ptr() for j in range(g)])
+            for j in range(g):
+                kept[i0 + j].copy_(bufs[j], non_blocking=True)
+    assert gpu.sync() == 0
+    torch.cuda.synchronize()
+    expect = oracle_frames(W, Hh, mesh, texs, "phong", p, band=band)
+    for i in range(n):
+        got = kept[i].cpu().numpy().reshape(Hh, W, 3)
+        assert np.array_equal(got[band[0]:band[1]], expect[i][0][band[0]:band[1]]), "frame %d" % i
+        assert (got[:band[0]] == 77).all() and (got[band[1]:] == 77).all(), "rows outside the band were written"
+    gpu.close()
+
+
+def test_group_with_winner_tap_and_profile(small_synthetic):
+    """The winner tap is one buffer: a call then goes frame by frame (same results, same slots).  The profile
+    counts the frames a launch covered."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh, n = 300, 200, 6
+    p = params(n)
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", winner_tap=True, frames_per_launch=4)
+    assert gpu.frames_per_launch == 1
+    gpu.render_frames(p)
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    cpu.clear(), cpu.set_light_direction(p[-1, 0:3]), cpu.set_camera(p[-1, 3:6], p[-1, 6:9], p[-1, 9:12]), cpu.render()
+    assert np.array_equal(gpu.read_winner_u32(), cpu.winner_u32())
+    assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer())
+    gpu.close()
+
+    gpu = T.Scene(W, Hh, mesh, texs, "shadow", frames_per_launch=4)
+    gpu.render_frames(p[:2])
+    gpu.sync()
+    gpu.profile_enable(True)
+    gpu.render_frames(p)          # groups of 4 + 2
+    prof = gpu.profile_read()
+    assert prof["k_tile"]["launches"] == 2 and prof["k_tile"]["frames"] == 6
+    assert prof["k_tile_depth"]["launches"] == 2 and prof["k_tile_depth"]["frames"] == 6
+    assert prof["k_setup"]["launches"] == 4 and prof["k_setup"]["frames"] == 12
+    assert len(gpu.profile_frame_intervals()) >= 2
+    gpu.profile_enable(False)
+    check_kept(gpu, oracle_frames(W, Hh, mesh, texs, "shadow", p), "shadow", n)
+    gpu.close()
+
+
+def test_full_size_group_equals_per_frame_path(diablo):
+    """4096^2 (BASELINE configs[2] geometry), automatic group size: every kept frame of a group call equals the
+    per-frame path's frame for the same light and camera (itself checked against the oracle at 800^2 /
+    2048^2 and by properties at this size)."""
+    import tiny_renderer_amd as T
+    mesh, texs = diablo
+    n = 6
+    p = params(n, cam_step=0.11)
+    gpu = T.Scene(4096, 4096, mesh, texs, "phong")
+    assert gpu.frames_per_launch == 4
+    gpu.render_frames(p)
+    one = T.Scene(4096, 4096, mesh, texs, "phong")
+    for back in range(gpu.frames_kept()):
+        q = p[n - 1 - back]
+        one.clear(), one.set_light_direction(q[0:3]), one.set_camera(q[3:6], q[6:9], q[9:12]), one.render()
+        gpu.select_frame(back)
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), one.read_z_f32().view(np.uint32))
+        assert np.array_equal(gpu.get_frame_buffer(), one.get_frame_buffer())
+    gpu.close()
+    one.close()

@@ -46,11 +46,16 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("band_row0", C.c_uint32), ("band_row1", C.c_uint32), ("stream", C.c_void_p),
                 ("frame_buffer_device", C.c_void_p), ("bin_capacity", C.c_uint64),
-                ("tile_waves", C.c_uint32), ("tile_mode", C.c_uint32)]
+                ("tile_waves", C.c_uint32), ("tile_mode", C.c_uint32), ("frames_per_launch", C.c_uint32)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("light", C.c_float * 3), ("look_from", C.c_float * 3), ("look_at", C.c_float * 3),
+                ("up", C.c_float * 3)]
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("frames", C.c_uint64)]
 
 
 class Uniforms(C.Structure):
@@ -70,6 +75,10 @@ SYMBOLS = {
     "tr_scene_set_light_direction": (C.c_int, [C.c_void_p, _FP]),
     "tr_scene_set_camera": (C.c_int, [C.c_void_p, _FP, _FP, _FP]),
     "tr_scene_render": (C.c_int, [C.c_void_p]),
+    "tr_scene_render_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "tr_scene_frames_per_launch": (C.c_int, [C.c_void_p]),
+    "tr_scene_frames_kept": (C.c_int, [C.c_void_p]),
+    "tr_scene_select_frame": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tr_scene_get_frame_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_get_frame_buffer_async": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_host_alloc": (C.c_void_p, [C.c_size_t]),

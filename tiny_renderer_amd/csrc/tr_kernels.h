@@ -12,15 +12,22 @@ namespace tr {
 // `start` / `done` (may be null) are attached to the kernel's own dispatch packet: `done` is
 // signalled by the kernel's completion without a separate event packet, and the pair brackets
 // exactly the kernel's execution when both are timing events.
-int launch_setup(int vs_kind, const SetupArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done);
+//
+// `group` (a table of n_frames argument structs in DEVICE memory; null = an ordinary launch) makes a launch a
+// FUSED one over a group of frames (tr_scene_render_frames): the workgroups of frame f take entry f of the
+// table; `a` (and `tile_count` / `order`) then only describe what the frames have in common -- mesh size,
+// tile grid, record layout, bin capacity -- to the launcher.  launch_order reads each frame's counters and
+// work list from the TILE kernel's table (TileArgs::tile_count_next is the frame's own counter set there).
+int launch_setup(int vs_kind, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st,
+                 hipEvent_t start, hipEvent_t done);
 // Builds the tile kernel's work list from the counters k_setup filled (same stream, after it).
-int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkItem *order, uint32_t n_tiles, hipStream_t st, hipEvent_t start,
-                 hipEvent_t done);
+int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkItem *order, uint32_t n_tiles,
+                 const TileArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
 // tile_waves: 4, 8 or 16 wavefronts per tile workgroup (see tr_types.h); shared != 0: the waves share the
 // tile's bin and resolve through atomic keys instead of each owning a column of the tile (k_tile's
 // SHARED parameter; falls back to columns when n_polygons or a.bin_cap exceed the key's fields).
-int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, hipStream_t st,
-                hipEvent_t start, hipEvent_t done);
+int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
+                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
 int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,

@@ -50,7 +50,7 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 constexpr uint32_t SETUP_POLYS = 16;  // polygons per 64-lane workgroup of k_setup
 
 template <int VS>
-__global__ __launch_bounds__(64) void k_setup(SetupArgs a)
+__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
 {
     constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     __shared__ uint4 s_rec[SETUP_POLYS * P];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
     // of tiles, and the wave with the most (polygon, tile) pairs is the kernel's critical path.
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = blockIdx.x * SETUP_POLYS + lane;
+    const uint32_t t = block * SETUP_POLYS + lane;
 
     int32_t tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
     uint32_t err = 0;
@@ -165,6 +165,26 @@ __global__ __launch_bounds__(64) void k_setup(SetupArgs a)
     }
 }
 
+template <int VS>
+__global__ __launch_bounds__(64) void k_setup(SetupArgs a)
+{
+    setup_body<VS>(a, blockIdx.x);
+}
+
+// Read-only argument tables of the fused launches: viewed in the constant address space, so that the loads
+// are scalar and invariant (a member is loaded where it is used, arrays are indexed in place) -- what the
+// compiler does with kernel arguments.
+template <typename T>
+using constant_ptr = const __attribute__((address_space(4))) T *;
+
+// The same for a group of frames in one launch (tr_scene_render_frames): blockIdx.y = frame, whose
+// arguments are entry y of a table in device memory.
+template <int VS>
+__global__ __launch_bounds__(64) void k_setup_group(const SetupArgs *__restrict__ table)
+{
+    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x);
+}
+
 // -----------------------------------------------------------------------------------------
 // k_order_count, k_order_place
 // -----------------------------------------------------------------------------------------
@@ -207,8 +227,12 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t n)
     return lg >= (uint32_t)(ORDER_BUCKETS - 2) ? 0u : (uint32_t)(ORDER_BUCKETS - 2) - lg;
 }
 
-__global__ __launch_bounds__(ORDER_THREADS) void k_order_count(uint32_t *tile_count, uint32_t n_tiles, uint32_t bits)
+// `group` != null: blockIdx.y = frame of a group, whose counters and work list are in entry y of the tile
+// kernel's argument table (TileArgs::tile_count_next is the frame's own counter set there).
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_count(uint32_t *tile_count, uint32_t n_tiles, uint32_t bits,
+                                                                const TileArgs *__restrict__ group)
 {
+    if (group) tile_count = group[blockIdx.y].tile_count_next;
     const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
     const bool live = i < n_tiles;
     const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
@@ -224,8 +248,12 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_count(uint32_t *tile_co
 }
 
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_place(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles,
-                                                                uint32_t bits)
+                                                                uint32_t bits, const TileArgs *__restrict__ group)
 {
+    if (group) {
+        tile_count = group[blockIdx.y].tile_count_next;
+        order = const_cast<WorkItem *>(group[blockIdx.y].order);
+    }
     const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const bool live = i < n_tiles;
@@ -374,9 +402,24 @@ __device__ __forceinline__ uint32_t depth_order_bits(float z)
 // carry equal loads wherever the polygons cluster (the eyes of a head at 800^2: one 8-pixel column
 // held 80 of a tile's 120 polygons and its wave ran 20 us while the others idled), and a polygon is
 // visited once per tile instead of once per column it touches.
-template <int FS, int TILE_WAVES, bool SHARED>
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES), tile_waves_per_eu(FS, TILE_WAVES)))) void k_tile(TileArgs a)
+#define TR_TILE_KERNEL_ATTRS \
+    __global__ __launch_bounds__(64 * TILE_WAVES) \
+        __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES), tile_waves_per_eu(FS, TILE_WAVES))))
+
+// GROUP = false: one frame, arguments by value.
+// GROUP = true: a fused launch over a group of n_frames frames (tr_scene_render_frames): workgroup b renders
+// entry b / n_frames of the work list of frame b % n_frames, whose arguments are entry b % n_frames of a
+// table in device memory -- so the heavy tiles of ALL the frames come first and the light and empty ones
+// fill the slots they free: one frame's drain (a third of a lone 4096^2 launch runs on a machine that is
+// emptying, and a small frame never fills it at all) is the next frame's start.
+template <int FS, int TILE_WAVES, bool SHARED, bool GROUP>
+TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ table, uint32_t n_frames)
 {
+    const uint32_t frame_of_group = GROUP ? blockIdx.x % n_frames : 0u;
+    const uint32_t work_index = GROUP ? blockIdx.x / n_frames : blockIdx.x;
+    // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
+    const TileArgs &a = GROUP ? *(const TileArgs *)((constant_ptr<TileArgs>)table + frame_of_group) : args;
+    uint64_t *const stamps = frame_of_group == 0u ? a.stamps : nullptr;  // the diagnostic stamps follow a group's first frame
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
     constexpr int QUAD_COLUMN = TILE_W / TILE_WAVES;  // width of a wave's column when columns are owned
@@ -402,11 +445,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // or letting the busy blocks issue those stores themselves, was 5-10 % slower.  Any order is
     // correct.  Every workgroup also zeroes its tile's counter for a later pass.
     const uint32_t tid = threadIdx.x;
-    const WorkItem work = a.order[blockIdx.x];
+    const WorkItem work = a.order[work_index];
     const uint32_t tile = work.tile;
     uint32_t n = work.count;
     if (tid == 0u) a.tile_count_next[tile] = 0u;
-    if (blockIdx.x == 0u && tid < 2u * (uint32_t)ORDER_BUCKETS)
+    if (work_index == 0u && tid < 2u * (uint32_t)ORDER_BUCKETS)
         a.tile_count_next[a.frame.ntx * a.frame.nty + tid] = 0u;  // k_order's bucket sizes and cursors
     if (n == 0u) {
         if (a.fresh) {
@@ -434,7 +477,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // Diagnostic builds of a scene (TR_OPT_TILE_STAMPS) record when each busy tile ran; the stamps
     // go to a buffer of their own and nothing is computed from them.
     uint64_t t_start = 0, t_staged = 0;
-    if (a.stamps) t_start = wall_clock64();
+    if (stamps) t_start = wall_clock64();
 
     float *depth = DEPTH ? a.shadow : a.zbuf;
     // is every z of this tile logically f32::MIN (cleared frame, or fast-clear flag still set)?
@@ -495,7 +538,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
             if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
             for (uint32_t q = tid; q < m * P; q += (uint32_t)TILE_THREADS) s_rec[q] = bin[(size_t)c0 * P + q];
             __syncthreads();
-            if (a.stamps && c0 == 0u) t_staged = wall_clock64();
+            if (stamps && c0 == 0u) t_staged = wall_clock64();
 
             // column mode: every wave takes all m records, 64 per round; shared mode: record jj belongs to
             // wave jj mod TILE_WAVES, a round covers 64 * TILE_WAVES records
@@ -682,7 +725,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         resolve(std::false_type{});
 
     uint64_t t_covered = 0;
-    if (a.stamps) t_covered = wall_clock64();
+    if (stamps) t_covered = wall_clock64();
 
     // ---- shade the survivors and stream the tile out ------------------------------------------
     // Lanes are row-major here: lane = x within a 32-pixel row; a step covers four rows, each
@@ -916,15 +959,15 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     if (a.zclean && tid == 0u) a.zclean[tile] = 0u;
     if (!DEPTH && a.fbclean && tid == 0u) a.fbclean[tile] = 0u;
 
-    if (a.stamps) {
+    if (stamps) {
         __syncthreads();
         if (tid == 0u) {
-            a.stamps[8u * tile + 0u] = t_start;
-            a.stamps[8u * tile + 1u] = wall_clock64();
-            a.stamps[8u * tile + 2u] = n;
-            a.stamps[8u * tile + 3u] = __smid();
-            a.stamps[8u * tile + 4u] = t_staged;
-            a.stamps[8u * tile + 5u] = t_covered;
+            stamps[8u * tile + 0u] = t_start;
+            stamps[8u * tile + 1u] = wall_clock64();
+            stamps[8u * tile + 2u] = n;
+            stamps[8u * tile + 3u] = __smid();
+            stamps[8u * tile + 4u] = t_staged;
+            stamps[8u * tile + 5u] = t_covered;
         }
     }
 }
@@ -1113,72 +1156,93 @@ int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned lo
 int rec_pieces_for_vs(int vs) { return vs == VS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 int rec_pieces_for_fs(int fs) { return fs == FS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 
-int launch_setup(int vs, const SetupArgs &a, hipStream_t st, hipEvent_t start, hipEvent_t done)
+int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start,
+                 hipEvent_t done)
 {
     if (a.mesh.n_tri == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
-    const dim3 grid((a.mesh.n_tri + SETUP_POLYS - 1u) / SETUP_POLYS), block(64);
+    if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
+    const dim3 grid((a.mesh.n_tri + SETUP_POLYS - 1u) / SETUP_POLYS, group ? n_frames : 1u), block(64);
+#define TR_SETUP_CASE(V)                                                                              \
+    case V:                                                                                           \
+        if (group)                                                                                    \
+            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group);       \
+        else                                                                                          \
+            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a);                 \
+        break;
     switch (vs) {
-    case VS_DEFAULT: hipExtLaunchKernelGGL(k_setup<VS_DEFAULT>, grid, block, 0, st, start, done, 0, a); break;
-    case VS_PHONG: hipExtLaunchKernelGGL(k_setup<VS_PHONG>, grid, block, 0, st, start, done, 0, a); break;
-    case VS_PLAIN: hipExtLaunchKernelGGL(k_setup<VS_PLAIN>, grid, block, 0, st, start, done, 0, a); break;
-    case VS_DARBOUX: hipExtLaunchKernelGGL(k_setup<VS_DARBOUX>, grid, block, 0, st, start, done, 0, a); break;
-    case VS_DEPTH: hipExtLaunchKernelGGL(k_setup<VS_DEPTH>, grid, block, 0, st, start, done, 0, a); break;
+    TR_SETUP_CASE(VS_DEFAULT)
+    TR_SETUP_CASE(VS_PHONG)
+    TR_SETUP_CASE(VS_PLAIN)
+    TR_SETUP_CASE(VS_DARBOUX)
+    TR_SETUP_CASE(VS_DEPTH)
     default: return (int)hipErrorInvalidValue;
     }
+#undef TR_SETUP_CASE
     TR_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, hipStream_t st, hipEvent_t start,
-                 hipEvent_t done)
+int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames,
+                 hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     if (n_tiles == 0) return 0;
-    const dim3 grid((n_tiles + ORDER_THREADS - 1u) / ORDER_THREADS), block(ORDER_THREADS);
+    if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
+    const dim3 grid((n_tiles + ORDER_THREADS - 1u) / ORDER_THREADS, group ? n_frames : 1u), block(ORDER_THREADS);
     uint32_t bits = 1;
     while ((1u << bits) < n_tiles) bits++;
-    hipExtLaunchKernelGGL(k_order_count, grid, block, 0, st, start, nullptr, 0, tile_count, n_tiles, bits);
+    hipExtLaunchKernelGGL(k_order_count, grid, block, 0, st, start, nullptr, 0, tile_count, n_tiles, bits, group);
     TR_LAUNCH_CHECK();
-    hipExtLaunchKernelGGL(k_order_place, grid, block, 0, st, nullptr, done, 0, tile_count, order, n_tiles, bits);
+    hipExtLaunchKernelGGL(k_order_place, grid, block, 0, st, nullptr, done, 0, tile_count, order, n_tiles, bits, group);
     TR_LAUNCH_CHECK();
     return 0;
 }
 
 template <int WAVES, bool SHARED>
-static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, hipStream_t st, hipEvent_t start, hipEvent_t done)
+static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames,
+                             hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
-    const dim3 grid(n_tiles), block(64 * WAVES);
+    const dim3 grid(n_tiles * (group ? n_frames : 1u)), block(64 * WAVES);
+#define TR_TILE_CASE(F)                                                                                                  \
+    case F:                                                                                                              \
+        if (group)                                                                                                       \
+            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, true>), grid, block, 0, st, start, done, 0, a, group, n_frames); \
+        else                                                                                                             \
+            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, false>), grid, block, 0, st, start, done, 0, a, nullptr, 0u); \
+        break;
     switch (fs) {
-    case FS_DEFAULT: hipExtLaunchKernelGGL((k_tile<FS_DEFAULT, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_PHONG: hipExtLaunchKernelGGL((k_tile<FS_PHONG, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_NORMAL_MAP: hipExtLaunchKernelGGL((k_tile<FS_NORMAL_MAP, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_SPECULAR: hipExtLaunchKernelGGL((k_tile<FS_SPECULAR, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_DARBOUX: hipExtLaunchKernelGGL((k_tile<FS_DARBOUX, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_SHADOW2: hipExtLaunchKernelGGL((k_tile<FS_SHADOW2, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_OCCLUSION2: hipExtLaunchKernelGGL((k_tile<FS_OCCLUSION2, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
-    case FS_DEPTH: hipExtLaunchKernelGGL((k_tile<FS_DEPTH, WAVES, SHARED>), grid, block, 0, st, start, done, 0, a); break;
+    TR_TILE_CASE(FS_DEFAULT)
+    TR_TILE_CASE(FS_PHONG)
+    TR_TILE_CASE(FS_NORMAL_MAP)
+    TR_TILE_CASE(FS_SPECULAR)
+    TR_TILE_CASE(FS_DARBOUX)
+    TR_TILE_CASE(FS_SHADOW2)
+    TR_TILE_CASE(FS_OCCLUSION2)
+    TR_TILE_CASE(FS_DEPTH)
     default: return (int)hipErrorInvalidValue;
     }
+#undef TR_TILE_CASE
     TR_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, hipStream_t st, hipEvent_t start,
-                hipEvent_t done)
+int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
+                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
+    if (group && (n_frames == 0 || (uint64_t)n_tiles * n_frames > 0x7FFFFFFFull)) return (int)hipErrorInvalidValue;
     // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns
     if (n_polygons > SHARED_MAX_POLYGONS || a.bin_cap > SHARED_MAX_SLOTS) shared = 0;
     if (shared) {
-        if (tile_waves == 16) return launch_tile_waves<16, true>(fs, a, n_tiles, st, start, done);
-        if (tile_waves == 8) return launch_tile_waves<8, true>(fs, a, n_tiles, st, start, done);
-        if (tile_waves == 4) return launch_tile_waves<4, true>(fs, a, n_tiles, st, start, done);
+        if (tile_waves == 16) return launch_tile_waves<16, true>(fs, a, n_tiles, group, n_frames, st, start, done);
+        if (tile_waves == 8) return launch_tile_waves<8, true>(fs, a, n_tiles, group, n_frames, st, start, done);
+        if (tile_waves == 4) return launch_tile_waves<4, true>(fs, a, n_tiles, group, n_frames, st, start, done);
     } else {
-        if (tile_waves == 16) return launch_tile_waves<16, false>(fs, a, n_tiles, st, start, done);
-        if (tile_waves == 8) return launch_tile_waves<8, false>(fs, a, n_tiles, st, start, done);
-        if (tile_waves == 4) return launch_tile_waves<4, false>(fs, a, n_tiles, st, start, done);
+        if (tile_waves == 16) return launch_tile_waves<16, false>(fs, a, n_tiles, group, n_frames, st, start, done);
+        if (tile_waves == 8) return launch_tile_waves<8, false>(fs, a, n_tiles, group, n_frames, st, start, done);
+        if (tile_waves == 4) return launch_tile_waves<4, false>(fs, a, n_tiles, group, n_frames, st, start, done);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -78,6 +78,7 @@ enum KernelId { K_SETUP = 0, K_TILE, K_TILE_DEPTH, K_CLEAR, K_ORDER, K_COUNT };
 struct EventPair {
     hipEvent_t a, b;
     int kernel;
+    uint32_t frames;  // frames the launch covered (fused launches of tr_scene_render_frames: more than one)
 };
 
 }  // namespace
@@ -111,6 +112,16 @@ constexpr int SETS = LOOKAHEAD + 1;
 // gives 34.2 (same box), and at small frames 25 -> 20.5 us (800^2), 24.8 -> 22.4 (2048^2).
 constexpr int BATCH = LOOKAHEAD - 1;  // passes that may be pending (setup queued, tile kernel not yet)
 constexpr int RING = 16;  // events: pass p's are waited for until pass p + LOOKAHEAD is set up
+
+// Frame groups (tr_scene_render_frames).  A lone frame cannot keep the GPU full: at 4096^2 a third of the tile
+// kernel runs on a machine that is draining (2 168 busy tiles on 1 536 workgroup slots), and smaller frames never
+// fill it at all; kernels of different launches do not overlap on this stack (profiles/r02_notes.md).  So the
+// frames of a group are rendered by ONE launch per kernel -- vertex stage + binning, work lists, tiles -- each
+// frame into a frame slot of its own (z, colour, fast-clear flags, shadow buffer).  Same replicated frame,
+// k_tile per frame (us, group of 1 / 2 / 4 / 8): 4096^2 phong 33.9 / 29.0 / 27.0 / 27.0, darboux 65.9 / 59.5 /
+// 58.9 / 56.3, 2048^2 phong 21.3 / 14.2 / 12.6 / 12.0, 800^2 26.3 / 12.8 / 7.4 / 4.5, 512^2 22.5 / 12.2 / 6.6 / 3.6.
+constexpr int GROUP_MAX = 16;   // frames per fused launch, at most
+constexpr int GROUP_SETS = 4;   // groups in flight: group g's setup reuses the bins of group g - GROUP_SETS
 
 struct tr_scene {
     uint32_t width = 0, height = 0;
@@ -176,9 +187,44 @@ struct tr_scene {
     // consumer the library cannot call back (an asynchronous read-back, or a caller's stream).
     unsigned long long *d_overflow_seq = nullptr;
     uint64_t observed_seq = 0;
+    // The current targets (aliases: the memory belongs to the frame slots below, or to the caller)
     float *d_z = nullptr, *d_shadow = nullptr;
     uint8_t *d_fb = nullptr;      // where the next render writes
-    uint8_t *d_fb_own = nullptr;  // the library's own buffer (allocated when first needed)
+    // Frame slots: complete sets of render targets.  Slot 0 is what the scene is created with; the others
+    // appear with the first tr_scene_render_frames, whose frame i goes to slot i % (frames per group).
+    // `fb` is the library's own colour buffer of the slot (allocated when first needed: callers may
+    // bring their own); slots of pipelines without a depth pass share slot 0's shadow buffer.
+    struct FrameSlot {
+        float *z = nullptr;
+        uint32_t *zclean = nullptr;
+        float *shadow = nullptr;
+        uint8_t *fb = nullptr;
+    };
+    std::vector<FrameSlot> slots;
+    int cur_slot = 0;
+    uint32_t frames_per_launch = 0;  // tr_options.frames_per_launch; 0 = by tile count
+    // One group in flight: bins, counters, work lists and argument tables of its frames' passes
+    struct GroupSet {
+        Piece *bins = nullptr;      // [pass][frame] x bin tiles x bin_cap records
+        uint32_t *count = nullptr;  // [pass][frame] x (n_tiles_full + 16)
+        WorkItem *order = nullptr;  // [pass][frame] x n_tiles_full
+        uint8_t *d_tables = nullptr, *h_tables = nullptr;  // [pass] x frames SetupArgs, then [pass] x frames TileArgs
+        hipEvent_t ev_setup = nullptr, ev_tile = nullptr;
+        bool in_flight = false;
+        uint32_t bin_cap = 0, frames = 0;  // what the set was allocated for
+        uint32_t g = 0;                    // frames of the group it holds now
+    } grp[GROUP_SETS];
+    uint64_t group_seq = 0;       // groups whose setup has been queued
+    uint64_t group_submitted = 0; // groups whose tile kernels have been queued (<= group_seq)
+    // The frames of the last tr_scene_render_frames call that still exist (the last `frames per group` of
+    // them): what tr_scene_select_frame chooses from, and what is rendered again after a bin overflow.
+    struct {
+        std::vector<tr_frame_params> params;
+        std::vector<void *> fbs;  // the caller's buffers, or empty
+        std::vector<int> slot;
+        uint64_t first_seq = 0;   // pass number of the first of them
+    } tail;
+    bool last_was_group = false;
     uint8_t *d_view = nullptr;  // scratch for get_z_buffer / get_shadow_buffer
     uint32_t *d_winner = nullptr;
     // Fast depth clear: one word per colour-pass tile, non-zero = "every z of the tile is f32::MIN,
@@ -222,6 +268,7 @@ struct tr_scene {
     std::vector<hipEvent_t> event_pool;
     double prof_ms[K_COUNT] = {};
     uint64_t prof_n[K_COUNT] = {};
+    uint64_t prof_frames[K_COUNT] = {};
     std::vector<float> frame_intervals_us;  // completion-to-completion time of consecutive colour-pass tile kernels
 };
 
@@ -243,29 +290,76 @@ void dev_free(T *&p)
 
 // Points d_fbclean at the flag set of the current frame buffer (allocated zeroed = "content unknown"
 // the first time a buffer is seen; at most a handful of buffers are remembered).
-int select_fb_flags(tr_scene *s)
+// The flag set of frame buffer `fb` (allocated zeroed = "content unknown" the first time a buffer is seen;
+// a few dozen buffers are remembered: a caller's double-buffered groups of frames, the scene's own slots).
+int fb_flags_for(tr_scene *s, uint8_t *fb, uint32_t **out)
 {
     for (const tr_scene::FbFlags &f : s->fb_flags)
-        if (f.fb == s->d_fb) {
-            // the winner tap is one buffer shared by all targets: its tiles were last written with
-            // another target's frame, so a remembered "clean" says nothing about them
-            if (s->d_winner && s->d_fbclean != f.clean)
-                HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
-            s->d_fbclean = f.clean;
+        if (f.fb == fb) {
+            *out = f.clean;
             return TR_OK;
         }
-    if (s->fb_flags.size() >= 8) {  // forget the oldest
+    if (s->fb_flags.size() >= 4u * GROUP_MAX + 8u) {  // forget the oldest that is not the current target's
         (void)hipStreamSynchronize(s->stream);
-        dev_free(s->fb_flags.front().clean);
-        s->fb_flags.erase(s->fb_flags.begin());
+        size_t k = 0;
+        while (k + 1 < s->fb_flags.size() && s->fb_flags[k].clean == s->d_fbclean) k++;
+        dev_free(s->fb_flags[k].clean);
+        s->fb_flags.erase(s->fb_flags.begin() + (long)k);
     }
-    tr_scene::FbFlags f = { s->d_fb, nullptr };
+    tr_scene::FbFlags f = { fb, nullptr };
     int st = dev_alloc(&f.clean, (size_t)s->n_tiles);
     if (st != TR_OK) return st;
     HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
     s->fb_flags.push_back(f);
-    s->d_fbclean = f.clean;
+    *out = f.clean;
     return TR_OK;
+}
+
+int select_fb_flags(tr_scene *s)
+{
+    uint32_t *clean = nullptr;
+    int st = fb_flags_for(s, s->d_fb, &clean);
+    if (st != TR_OK) return st;
+    // the winner tap is one buffer shared by all targets: its tiles were last written with another
+    // target's frame, so a remembered "clean" says nothing about them
+    if (s->d_winner && s->d_fbclean != clean) HIP_TRY(hipMemsetAsync(clean, 0, (size_t)s->n_tiles * 4, s->stream));
+    s->d_fbclean = clean;
+    return TR_OK;
+}
+
+// The library's own colour buffer of a slot, zero-filled when it is created (Scene::new, scene.rs:71).
+int slot_own_fb(tr_scene *s, int k, uint8_t **out)
+{
+    tr_scene::FrameSlot &fs = s->slots[(size_t)k];
+    if (!fs.fb) {
+        const size_t n = (size_t)s->width * s->height * 3;
+        int st = dev_alloc(&fs.fb, n);
+        if (st != TR_OK) return st;
+        HIP_TRY(hipMemsetAsync(fs.fb, 0, n, s->stream));
+        uint32_t *clean = nullptr;
+        st = fb_flags_for(s, fs.fb, &clean);
+        if (st != TR_OK) return st;
+        if (!s->d_winner) HIP_TRY(hipMemsetAsync(clean, 0xFF, (size_t)s->n_tiles * 4, s->stream));  // zeros = the cleared colour
+    }
+    *out = fs.fb;
+    return TR_OK;
+}
+
+// Makes slot k the current set of targets; colour goes to `fb` (a caller's buffer) or, if null, to the
+// slot's own buffer.
+int use_slot(tr_scene *s, int k, uint8_t *fb)
+{
+    const tr_scene::FrameSlot &fs = s->slots[(size_t)k];
+    s->cur_slot = k;
+    s->d_z = fs.z;
+    s->d_zclean = fs.zclean;
+    s->d_shadow = fs.shadow;
+    if (!fb) {
+        int st = slot_own_fb(s, k, &fb);
+        if (st != TR_OK) return st;
+    }
+    s->d_fb = fb;
+    return select_fb_flags(s);
 }
 
 hipEvent_t take_event(tr_scene *s)
@@ -288,6 +382,7 @@ struct Timed {
     Timed(tr_scene *sc, int kernel, hipStream_t stream = nullptr) : s(sc), st(stream ? stream : sc->stream), on(false)
     {
         ep.kernel = kernel;
+        ep.frames = 1u;
         ep.a = ep.b = nullptr;
         if (s->profiling && s->events.size() < (1u << 20)) {
             ep.a = take_event(s);
@@ -309,13 +404,15 @@ int drain_events(tr_scene *s)
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             s->prof_ms[ep.kernel] += ms;
             s->prof_n[ep.kernel] += 1;
+            s->prof_frames[ep.kernel] += ep.frames;
         }
         if (ep.kernel == K_TILE) {
             // a frame ends with its colour pass: the spacing of those completions is the frame time
-            // of the running pipeline (frames overlap; a kernel's own duration says less)
-            if (prev_frame_end && hipEventElapsedTime(&ms, prev_frame_end, ep.b) == hipSuccess &&
-                s->frame_intervals_us.size() < (1u << 20))
-                s->frame_intervals_us.push_back(ms * 1000.0f);
+            // of the running pipeline (frames overlap; a kernel's own duration says less); a fused
+            // launch completes its frames together: each gets an equal share of the spacing
+            if (prev_frame_end && hipEventElapsedTime(&ms, prev_frame_end, ep.b) == hipSuccess)
+                for (uint32_t k = 0; k < ep.frames && s->frame_intervals_us.size() < (1u << 20); k++)
+                    s->frame_intervals_us.push_back(ms * 1000.0f / (float)ep.frames);
             prev_frame_end = ep.b;
         }
         s->event_pool.push_back(ep.a);
@@ -336,11 +433,11 @@ int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
 {
     int status = TR_OK;
     if (!s->profiling) {
-        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
+        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
         if (rc) status = launch_status(rc, "k_tile");
     } else {
-        EventPair ep = { take_event(s), take_event(s), t.kernel_id };
-        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, s->stream, ep.a, ep.b);
+        EventPair ep = { take_event(s), take_event(s), t.kernel_id, 1u };
+        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, ep.a, ep.b);
         if (rc) status = launch_status(rc, "k_tile");
         s->events.push_back(ep);
         if (hipEventRecord(s->ev_tile[t.p_seq % RING], s->stream) != hipSuccess && status == TR_OK)
@@ -438,6 +535,7 @@ int materialize_depth(tr_scene *s)
 }
 
 int render_frame(tr_scene *s);
+int replay_tail(tr_scene *s);
 
 // Tiles the bins must cover: a band scene's colour passes touch its own rows only; the depth passes of
 // shadow / occlusion fill the whole shadow buffer on every rank (shader.rs:774-778).
@@ -469,8 +567,13 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     while (cap < need) cap *= 2;
     if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
     if (cap < need) cap = need;
-    if ((uint64_t)LOOKAHEAD * cap * (uint64_t)bin_tiles(s) * s->rec_pieces * 16ull > (64ull << 30))
-        return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 64 GiB");
+    {
+        // per-frame sets + the frame groups' sets, if they exist
+        uint64_t sets = LOOKAHEAD;
+        for (const tr_scene::GroupSet &g : s->grp) sets += (uint64_t)g.frames * (uint64_t)kPipelines[s->pipeline].n_passes;
+        if (sets * cap * (uint64_t)bin_tiles(s) * s->rec_pieces * 16ull > (128ull << 30))
+            return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 128 GiB");
+    }
     HIP_TRY(hipStreamSynchronize(s->setup_stream));
     s->bin_cap = (uint32_t)cap;
     int st = TR_OK;
@@ -479,10 +582,12 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
         st = dev_alloc(&s->d_bins[k], (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces);
     }
     if (st != TR_OK) return st;
+    // (the frame groups' bins follow bin_cap when their set is next used)
     if (first_bad_seq < s->observed_seq)
         return tr::fail(TR_E_BIN_OVERFLOW,
                         "triangle bins overflowed in a frame that was already handed on (asynchronous read-back or "
                         "caller's stream): that frame is truncated; the bins have been grown: render it again");
+    if (s->last_was_group) return replay_tail(s);  // frames older than the tail no longer exist anywhere
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
     if (!replayable)
@@ -570,18 +675,39 @@ void fill_dev_uniforms(const tr_scene *s, DevUniforms &d)
     memset(d.occl_steps, 0, sizeof d.occl_steps);
 }
 
-int run_pass(tr_scene *s, const PassDesc &p)
+// The frame constants of one pass (shader.rs:183-279 prepares) for the light and camera the scene holds.
+int pass_uniforms(tr_scene *s, const PassDesc &p, DevUniforms &du)
 {
     int st = prepare_uniforms(p.prepare_kind, &s->uniforms, s->width, s->height, s->light, s->from, s->at, s->up);
     if (st != TR_OK) return tr::fail(st, "prepare: singular matrix (try_inverse().unwrap() would panic)");
-
-    DevUniforms du;
     fill_dev_uniforms(s, du);
     if (p.fs == FS_SHADOW2 || p.fs == FS_OCCLUSION2) shadow_times_inverse(&s->uniforms, du.sm_ivpmv);
     if (p.fs == FS_OCCLUSION2) {
         st = occlusion_steps(&s->uniforms, du.occl_steps);
         if (st != TR_OK) return tr::fail(st, "occlusion: rotation_between(..).unwrap() would panic");
     }
+    return TR_OK;
+}
+
+// How a tile's work is divided is a launch-time choice (speed only; tr_options.tile_waves / tile_mode
+// pin it).  Few tiles cannot fill the GPU with four waves each: more waves per tile shorten every
+// wave's serial chain, and sharing the bin between them (instead of giving each a column of the
+// tile) keeps them equally loaded where polygons cluster.  Many tiles fill the GPU anyway: four
+// waves with private columns do the least total work.  Measured on diablo / phong (k_tile us, best
+// of the six combinations per size, profiles/r02_notes.md): 512^2 24.8 (16 shared; 4 columns 129),
+// 1024^2 22.2 (16 shared), 2048^2 21.9 (8 shared), 2560^2 23.2 (8 columns), 4096^2 33.1 (4 columns).
+// `tiles_in_launch` counts the tiles of ALL the frames of a fused launch.
+void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, int &tile_waves, int &shared)
+{
+    tile_waves = s->tile_waves ? (int)s->tile_waves : tiles_in_launch <= 1024u ? 16 : tiles_in_launch <= 4608u ? 8 : 4;
+    shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto(tiles_in_launch <= 2048u ? 1 : 0);
+}
+
+int run_pass(tr_scene *s, const PassDesc &p)
+{
+    DevUniforms du;
+    int st = pass_uniforms(s, p, du);
+    if (st != TR_OK) return st;
 
     const bool depth_pass = (p.fs == FS_DEPTH);
     // Which targets does this pass write, and are they logically cleared?
@@ -622,19 +748,19 @@ int run_pass(tr_scene *s, const PassDesc &p)
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
     const uint32_t n_tiles_pass = frame.ntx * frame.nty;
     if (!s->profiling) {
-        int rc = launch_setup(p.vs, sa, s->setup_stream, nullptr, nullptr);
+        int rc = launch_setup(p.vs, sa, nullptr, 0, s->setup_stream, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, s->setup_stream, nullptr,
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, s->setup_stream, nullptr,
                           s->ev_setup[p_seq % RING]);
         if (rc) return launch_status(rc, "k_order");
     } else {
         // profiling: timing events on the dispatches themselves, then the pipeline's event separately
-        EventPair ep = { take_event(s), take_event(s), K_SETUP };
-        int rc = launch_setup(p.vs, sa, s->setup_stream, ep.a, ep.b);
+        EventPair ep = { take_event(s), take_event(s), K_SETUP, 1u };
+        int rc = launch_setup(p.vs, sa, nullptr, 0, s->setup_stream, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
         if (s->mesh.n_tri) s->events.push_back(ep);
-        EventPair eo = { take_event(s), take_event(s), K_ORDER };
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, s->setup_stream, eo.a, eo.b);
+        EventPair eo = { take_event(s), take_event(s), K_ORDER, 1u };
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, s->setup_stream, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
         s->events.push_back(eo);
         HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], s->setup_stream));
@@ -659,19 +785,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
-    // How a tile's work is divided is a launch-time choice (speed only; tr_options.tile_waves / tile_mode
-    // pin it).  Few tiles cannot fill the GPU with four waves each: more waves per tile shorten every
-    // wave's serial chain, and sharing the bin between them (instead of giving each a column of the
-    // tile) keeps them equally loaded where polygons cluster.  Many tiles fill the GPU anyway: four
-    // waves with private columns do the least total work.  Measured on diablo / phong (k_tile us, best
-    // of the six combinations per size, profiles/r02_notes.md): 512^2 24.8 (16 shared; 4 columns 129),
-    // 1024^2 22.2 (16 shared), 2048^2 21.9 (8 shared), 2560^2 23.2 (8 columns), 4096^2 33.1 (4 columns).
-    const int tile_waves = s->tile_waves ? (int)s->tile_waves : n_tiles_pass <= 1024u ? 16 : n_tiles_pass <= 4608u ? 8 : 4;
-    const int shared_auto = n_tiles_pass <= 2048u ? 1 : 0;
     tr_scene::PendingTile pt;
     pt.fs = p.fs;
-    pt.tile_waves = tile_waves;
-    pt.shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto(shared_auto);
+    tile_layout(s, n_tiles_pass, pt.tile_waves, pt.shared);
     pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
     pt.p_seq = p_seq;
     pt.args = ta;
@@ -720,6 +836,337 @@ int render_frame(tr_scene *s)
     return TR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Frame groups (tr_scene_render_frames)
+// ---------------------------------------------------------------------------------------------
+
+// Frames per fused launch: enough tiles to keep the machine full while one frame's light tiles drain
+// (from 16 K tiles per launch the replicated-frame experiment above gains nothing more), within
+// GROUP_MAX; at least four frames.  The winner tap and the tile stamps are single buffers: one frame.
+uint32_t group_size(const tr_scene *s)
+{
+    static const int forced = getenv("TR_GROUP") ? atoi(getenv("TR_GROUP")) : 0;  // experiment hook
+    if (s->d_winner) return 1u;
+    if (forced >= 1 && forced <= GROUP_MAX) return (uint32_t)forced;
+    if (s->frames_per_launch) return s->frames_per_launch;
+    uint32_t g = s->n_tiles ? 16384u / s->n_tiles : (uint32_t)GROUP_MAX;
+    return g < 4u ? 4u : g > (uint32_t)GROUP_MAX ? (uint32_t)GROUP_MAX : g;
+}
+
+// Frame slots 1 .. n - 1 (slot 0 exists since tr_scene_create).  Their z memory needs no initial value:
+// a slot is only ever reached through a group's cleared frame, which writes every tile or raises its flag.
+int ensure_slots(tr_scene *s, uint32_t n)
+{
+    const size_t npx = (size_t)s->width * s->height;
+    while (s->slots.size() < n) {
+        tr_scene::FrameSlot fs;
+        int st = dev_alloc(&fs.z, npx);
+        if (st == TR_OK) st = dev_alloc(&fs.zclean, (size_t)s->n_tiles);
+        if (st == TR_OK && kPipelines[s->pipeline].n_passes == 2) st = dev_alloc(&fs.shadow, npx);
+        if (st != TR_OK) {
+            dev_free(fs.z);
+            dev_free(fs.zclean);
+            dev_free(fs.shadow);
+            return st;
+        }
+        if (!fs.shadow) fs.shadow = s->slots[0].shadow;  // never written without a depth pass
+        s->slots.push_back(fs);
+    }
+    return TR_OK;
+}
+
+size_t group_bins_per_frame(const tr_scene *s) { return (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces; }
+size_t group_counts_per_frame(const tr_scene *s) { return (size_t)s->n_tiles_full + 16u; }
+
+int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
+{
+    const size_t np = (size_t)kPipelines[s->pipeline].n_passes;
+    if (!gs.ev_setup) {
+        HIP_TRY(hipEventCreateWithFlags(&gs.ev_setup, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&gs.ev_tile, hipEventDisableTiming));
+    }
+    int st = TR_OK;
+    if (gs.frames < frames) {
+        dev_free(gs.count);
+        dev_free(gs.order);
+        dev_free(gs.d_tables);
+        if (gs.h_tables) (void)hipHostFree(gs.h_tables);
+        gs.h_tables = nullptr;
+        dev_free(gs.bins);
+        gs.bin_cap = 0;
+        gs.frames = 0;
+        const size_t nc = np * frames * group_counts_per_frame(s);
+        if ((st = dev_alloc(&gs.count, nc))) return st;
+        HIP_TRY(hipMemset(gs.count, 0, nc * 4));  // from here on every tile kernel zeroes its own frame's counters
+        if ((st = dev_alloc(&gs.order, np * frames * (size_t)s->n_tiles_full))) return st;
+        const size_t tb = np * frames * (sizeof(SetupArgs) + sizeof(TileArgs));
+        if ((st = dev_alloc(&gs.d_tables, tb))) return st;
+        HIP_TRY(hipHostMalloc((void **)&gs.h_tables, tb, hipHostMallocDefault));
+        gs.frames = frames;
+    }
+    if (gs.bin_cap != s->bin_cap) {
+        dev_free(gs.bins);
+        gs.bin_cap = 0;
+        if ((st = dev_alloc(&gs.bins, np * gs.frames * group_bins_per_frame(s)))) return st;
+        gs.bin_cap = s->bin_cap;
+    }
+    return TR_OK;
+}
+
+int submit_groups(tr_scene *s, bool all);
+
+// Queues the setup of g <= frames-per-group cleared frames, one launch per kernel and pass.  Frame j takes
+// light and camera from p[j], its targets from slot slot_of[j] and its colour buffer from fbs[j] (fbs == null:
+// the slot's own).  The tile kernels follow with submit_groups.
+int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int *slot_of, uint32_t g)
+{
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    const uint32_t np = (uint32_t)pd.n_passes;
+    tr_scene::GroupSet &gs = s->grp[s->group_seq % GROUP_SETS];
+    // the set's previous group must have left the GPU before its bins, counters and tables are written again;
+    // this wait is also what keeps the host from running ahead of the GPU without bound
+    if (gs.in_flight) {
+        if (s->group_seq - s->group_submitted >= (uint64_t)GROUP_SETS) {  // (cannot happen: submit_groups holds back two at most)
+            int sg = submit_groups(s, true);
+            if (sg != TR_OK) return sg;
+        }
+        HIP_TRY(hipEventSynchronize(gs.ev_tile));
+    }
+    gs.in_flight = false;
+    int st = ensure_group_set(s, gs, group_size(s));
+    if (st != TR_OK) return st;
+    const uint32_t G = gs.frames;
+    if (g == 0 || g > G) return tr::fail(TR_E_INVALID, "group larger than its set");
+
+    SetupArgs *h_setup = reinterpret_cast<SetupArgs *>(gs.h_tables);
+    TileArgs *h_tile = reinterpret_cast<TileArgs *>(gs.h_tables + (size_t)np * G * sizeof(SetupArgs));
+    const SetupArgs *d_setup = reinterpret_cast<const SetupArgs *>(gs.d_tables);
+    const TileArgs *d_tile = reinterpret_cast<const TileArgs *>(gs.d_tables + (size_t)np * G * sizeof(SetupArgs));
+
+    float keep[12];
+    memcpy(keep, s->light, 12); memcpy(keep + 3, s->from, 12); memcpy(keep + 6, s->at, 12); memcpy(keep + 9, s->up, 12);
+    for (uint32_t j = 0; j < g && st == TR_OK; j++) {
+        memcpy(s->light, p[j].light, 12); memcpy(s->from, p[j].look_from, 12);
+        memcpy(s->at, p[j].look_at, 12); memcpy(s->up, p[j].up, 12);
+        const tr_scene::FrameSlot &slot = s->slots[(size_t)slot_of[j]];
+        uint8_t *fb = fbs ? (uint8_t *)fbs[j] : nullptr;
+        if (!fb) st = slot_own_fb(s, slot_of[j], &fb);
+        uint32_t *fbclean = nullptr;
+        if (st == TR_OK) st = fb_flags_for(s, fb, &fbclean);
+        for (uint32_t pi = 0; pi < np && st == TR_OK; pi++) {
+            const PassDesc &pass = pd.pass[pi];
+            const bool depth_pass = (pass.fs == FS_DEPTH);
+            const size_t e = (size_t)pi * G + j;  // this frame-pass's share of the set
+            SetupArgs &sa = h_setup[e];
+            TileArgs &ta = h_tile[e];
+            memset(&sa, 0, sizeof sa);
+            memset(&ta, 0, sizeof ta);
+            st = pass_uniforms(s, pass, sa.u);
+            if (st != TR_OK) break;
+            const DevFrame &frame = depth_pass ? s->frame_full : s->frame;
+            sa.mesh = s->mesh;
+            sa.frame = frame;
+            sa.tile_count = gs.count + e * group_counts_per_frame(s);
+            sa.bins = gs.bins + e * group_bins_per_frame(s);
+            sa.bin_cap = s->bin_cap;
+            sa.rec_pieces = s->rec_pieces;
+            sa.bin_need = s->d_bin_need;
+            sa.err = s->d_err;
+            sa.overflow_seq = s->d_overflow_seq;
+            sa.pass_seq = s->pass_seq + (uint64_t)j * np + pi;  // frame by frame, as the per-frame path numbers them
+            ta.bins = sa.bins;
+            ta.bin_cap = s->bin_cap;
+            ta.rec_pieces = s->rec_pieces;
+            ta.order = gs.order + e * (size_t)s->n_tiles_full;
+            ta.tile_count_next = sa.tile_count;  // dead once the work list exists: the tile kernel zeroes them for the set's next group
+            ta.frame = frame;
+            ta.u = sa.u;
+            ta.tex = s->tex;
+            ta.zbuf = slot.z;
+            ta.shadow = slot.shadow;
+            ta.fb = fb;
+            ta.winner = nullptr;
+            ta.zclean = depth_pass ? nullptr : slot.zclean;
+            ta.fbclean = depth_pass ? nullptr : fbclean;
+            ta.err = s->d_err;
+            ta.fresh = 1u;  // every frame of a group starts from cleared targets
+            ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
+            ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
+            ta.stamps = depth_pass ? nullptr : s->d_stamps;
+        }
+    }
+    memcpy(s->light, keep, 12); memcpy(s->from, keep + 3, 12); memcpy(s->at, keep + 6, 12); memcpy(s->up, keep + 9, 12);
+    if (st != TR_OK) return st;
+
+    // tables to the device, then per pass: vertex stage + binning of all frames, their work lists
+    HIP_TRY(hipMemcpyAsync(gs.d_tables, gs.h_tables, (size_t)np * G * (sizeof(SetupArgs) + sizeof(TileArgs)),
+                           hipMemcpyHostToDevice, s->setup_stream));
+    for (uint32_t pi = 0; pi < np; pi++) {
+        const PassDesc &pass = pd.pass[pi];
+        const SetupArgs &sa0 = h_setup[(size_t)pi * G];
+        const uint32_t n_tiles_pass = sa0.frame.ntx * sa0.frame.nty;
+        EventPair ep = { nullptr, nullptr, K_SETUP, g }, eo = { nullptr, nullptr, K_ORDER, g };
+        if (s->profiling) {
+            ep.a = take_event(s); ep.b = take_event(s);
+            eo.a = take_event(s); eo.b = take_event(s);
+        }
+        int rc = launch_setup(pass.vs, sa0, d_setup + (size_t)pi * G, g, s->setup_stream, ep.a, ep.b);
+        if (rc) return launch_status(rc, "k_setup");
+        rc = launch_order(nullptr, nullptr, n_tiles_pass, d_tile + (size_t)pi * G, g, s->setup_stream, eo.a, eo.b);
+        if (rc) return launch_status(rc, "k_order");
+        if (s->profiling) {
+            if (s->mesh.n_tri) s->events.push_back(ep);
+            s->events.push_back(eo);
+        }
+    }
+    HIP_TRY(hipEventRecord(gs.ev_setup, s->setup_stream));
+    gs.g = g;
+    gs.in_flight = true;
+    s->pass_seq += (uint64_t)g * np;
+    s->group_seq++;
+    return TR_OK;
+}
+
+// The tile kernels of the oldest group whose setup is queued, pass by pass (a colour pass reads what its
+// frame's depth pass wrote), behind a wait for that setup unless the caller knows it has completed.
+int submit_group_tiles(tr_scene *s, bool wait_for_setup)
+{
+    if (s->group_submitted == s->group_seq) return TR_OK;
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    const uint32_t np = (uint32_t)pd.n_passes;
+    tr_scene::GroupSet &gs = s->grp[s->group_submitted % GROUP_SETS];
+    const uint32_t G = gs.frames, g = gs.g;
+    const TileArgs *h_tile = reinterpret_cast<const TileArgs *>(gs.h_tables + (size_t)np * G * sizeof(SetupArgs));
+    const TileArgs *d_tile = reinterpret_cast<const TileArgs *>(gs.d_tables + (size_t)np * G * sizeof(SetupArgs));
+    s->group_submitted++;
+    if (wait_for_setup) HIP_TRY(hipStreamWaitEvent(s->stream, gs.ev_setup, 0));
+    for (uint32_t pi = 0; pi < np; pi++) {
+        const PassDesc &pass = pd.pass[pi];
+        const TileArgs &ta0 = h_tile[(size_t)pi * G];
+        int tile_waves = 4, shared = 0;
+        tile_layout(s, (uint64_t)ta0.frame.ntx * ta0.frame.nty * g, tile_waves, shared);
+        EventPair ep = { nullptr, nullptr, pass.fs == FS_DEPTH ? K_TILE_DEPTH : K_TILE, g };
+        if (s->profiling) {
+            ep.a = take_event(s);
+            ep.b = take_event(s);
+        }
+        int rc = launch_tile(pass.fs, ta0, tile_waves, shared, s->mesh.n_tri, d_tile + (size_t)pi * G, g, s->stream, ep.a, ep.b);
+        if (rc) return launch_status(rc, "k_tile");
+        if (s->profiling) s->events.push_back(ep);
+    }
+    HIP_TRY(hipEventRecord(gs.ev_tile, s->stream));
+    if (!s->own_stream) s->observed_seq = s->pass_seq;  // a caller's stream: handed on (see recover_from_overflow)
+    return TR_OK;
+}
+
+// Hands groups to the main stream, oldest first.  As with single frames ("Handing tile kernels to the main
+// stream" above) a cross-stream wait packet between two tile kernels costs microseconds and is not needed
+// when the setup has already completed, so inside a long call a group's tile kernels go out one or two
+// groups after its setup was queued -- by then the setup stream, which runs in the gaps and tails of the tile
+// kernels before, has finished it.  `all`: the end of a call -- everything goes out, behind a wait if need be.
+int submit_groups(tr_scene *s, bool all)
+{
+    int status = TR_OK;
+    while (s->group_submitted < s->group_seq) {
+        tr_scene::GroupSet &gs = s->grp[s->group_submitted % GROUP_SETS];
+        const bool ready = hipEventQuery(gs.ev_setup) == hipSuccess;
+        // two groups held back at most: the next setup needs the set of group_seq - GROUP_SETS, whose tile
+        // kernels must be on the stream by then
+        if (!ready && !all && s->group_seq - s->group_submitted <= 2) break;
+        int st = submit_group_tiles(s, !ready);
+        if (st != TR_OK && status == TR_OK) status = st;
+    }
+    return status;
+}
+
+// Groups are done: later per-frame passes set up on the setup stream reuse the per-frame bins, which the tile
+// kernels queued so far may still read -- order the setup stream behind the main stream once.
+int fence_setup_stream(tr_scene *s)
+{
+    int st = submit_groups(s, true);
+    if (st != TR_OK) return st;
+    const tr_scene::GroupSet &gs = s->grp[(s->group_seq + GROUP_SETS - 1) % GROUP_SETS];
+    if (gs.in_flight) HIP_TRY(hipStreamWaitEvent(s->setup_stream, gs.ev_tile, 0));
+    return TR_OK;
+}
+
+// n cleared frames, frame i into slot i % G; afterwards the last one is the scene's current frame.
+int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const *fbs)
+{
+    int st = submit_pending(s);  // per-frame renders issued before go first
+    if (st != TR_OK) return st;
+    const uint32_t G = group_size(s);
+    if ((st = ensure_slots(s, G < n ? G : n)) != TR_OK) return st;
+    s->host_status = TR_OK;
+    const uint64_t first_seq = s->pass_seq;
+    const uint32_t np = (uint32_t)kPipelines[s->pipeline].n_passes;
+    if (s->d_winner) {
+        // the winner tap is a single buffer: frame by frame through the ordinary path, slots all the same
+        for (uint32_t i = 0; i < n; i++) {
+            if ((st = use_slot(s, (int)(i % G), fbs ? (uint8_t *)fbs[i] : nullptr)) != TR_OK) return st;
+            memcpy(s->light, p[i].light, 12); memcpy(s->from, p[i].look_from, 12);
+            memcpy(s->at, p[i].look_at, 12); memcpy(s->up, p[i].up, 12);
+            s->z_fb_cleared = s->shadow_cleared = true;
+            if ((st = render_frame(s)) != TR_OK) return st;
+        }
+    } else {
+        int slot_of[GROUP_MAX];
+        for (uint32_t j = 0; j < (uint32_t)GROUP_MAX; j++) slot_of[j] = (int)j;
+        for (uint32_t i0 = 0; i0 < n; i0 += G) {
+            const uint32_t g = n - i0 < G ? n - i0 : G;
+            st = run_group(s, p + i0, fbs ? fbs + i0 : nullptr, slot_of, g);
+            if (st == TR_OK) st = submit_groups(s, false);
+            if (st != TR_OK) {
+                (void)submit_groups(s, true);
+                s->host_status = st;
+                return st;
+            }
+        }
+        if ((st = fence_setup_stream(s)) != TR_OK) return st;
+        // the scene now stands where the per-frame calls would have left it
+        const tr_frame_params &l = p[n - 1];
+        memcpy(s->light, l.light, 12); memcpy(s->from, l.look_from, 12); memcpy(s->at, l.look_at, 12); memcpy(s->up, l.up, 12);
+        s->z_fb_cleared = s->shadow_cleared = false;
+        if ((st = use_slot(s, (int)((n - 1) % G), fbs ? (uint8_t *)fbs[n - 1] : nullptr)) != TR_OK) return st;
+    }
+    // what is left of the call: its last min(n, G) frames
+    const uint32_t kept = n < G ? n : G;
+    s->tail.params.assign(p + (n - kept), p + n);
+    s->tail.fbs.clear();
+    if (fbs) s->tail.fbs.assign(fbs + (n - kept), fbs + n);
+    s->tail.slot.resize(kept);
+    for (uint32_t k = 0; k < kept; k++) s->tail.slot[k] = (int)((n - kept + k) % G);
+    s->tail.first_seq = first_seq + (uint64_t)(n - kept) * np;
+    s->last_was_group = true;
+    s->last.valid = false;
+    return TR_OK;
+}
+
+// After a bin overflow: the frames of the last call that still exist, again (the bins have grown).
+int replay_tail(tr_scene *s)
+{
+    const uint32_t kept = (uint32_t)s->tail.params.size();
+    if (kept == 0) return TR_OK;
+    const int cur = s->cur_slot;
+    uint8_t *cur_fb = s->d_fb;
+    int st = TR_OK;
+    if (s->d_winner) {
+        for (uint32_t k = 0; k < kept && st == TR_OK; k++) {
+            st = use_slot(s, s->tail.slot[k], s->tail.fbs.empty() ? nullptr : (uint8_t *)s->tail.fbs[k]);
+            const tr_frame_params &q = s->tail.params[k];
+            memcpy(s->light, q.light, 12); memcpy(s->from, q.look_from, 12); memcpy(s->at, q.look_at, 12); memcpy(s->up, q.up, 12);
+            s->z_fb_cleared = s->shadow_cleared = true;
+            if (st == TR_OK) st = render_frame(s);
+        }
+    } else {
+        st = run_group(s, s->tail.params.data(), s->tail.fbs.empty() ? nullptr : s->tail.fbs.data(), s->tail.slot.data(), kept);
+        if (st == TR_OK) st = fence_setup_stream(s);
+    }
+    if (st != TR_OK) return st;
+    return use_slot(s, cur, cur_fb == s->slots[(size_t)cur].fb ? nullptr : cur_fb);  // the selection the caller had
+}
+
 int find_pipeline(const char *name)
 {
     if (!name) return -1;
@@ -759,12 +1206,24 @@ void destroy(tr_scene *s)
     }
     dev_free(s->d_bin_need);
     dev_free(s->d_overflow_seq);
-    dev_free(s->d_z);
-    dev_free(s->d_shadow);
-    dev_free(s->d_fb_own);
+    for (size_t k = s->slots.size(); k-- > 0;) {  // slot 0 last: the others may share its shadow buffer
+        tr_scene::FrameSlot &fs = s->slots[k];
+        dev_free(fs.z);
+        dev_free(fs.zclean);
+        if (k == 0 || fs.shadow != s->slots[0].shadow) dev_free(fs.shadow);
+        dev_free(fs.fb);
+    }
+    for (tr_scene::GroupSet &g : s->grp) {
+        dev_free(g.bins);
+        dev_free(g.count);
+        dev_free(g.order);
+        dev_free(g.d_tables);
+        if (g.h_tables) (void)hipHostFree(g.h_tables);
+        if (g.ev_setup) (void)hipEventDestroy(g.ev_setup);
+        if (g.ev_tile) (void)hipEventDestroy(g.ev_tile);
+    }
     dev_free(s->d_view);
     dev_free(s->d_winner);
-    dev_free(s->d_zclean);
     for (tr_scene::FbFlags &f : s->fb_flags) dev_free(f.clean);
     dev_free(s->d_stamps);
     dev_free(s->d_err);
@@ -813,6 +1272,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->tile_waves = o.tile_waves;
     if (o.tile_mode > 2) return tr::fail(TR_E_INVALID, "tile_mode must be 0 (automatic), 1 (columns) or 2 (shared bin)");
     s->tile_mode = o.tile_mode;
+    if (o.frames_per_launch > (uint32_t)GROUP_MAX) return tr::fail(TR_E_INVALID, "frames_per_launch must be 0 (automatic) or 1..16");
+    s->frames_per_launch = o.frames_per_launch;
 
     if (o.stream) {
         s->stream = (hipStream_t)o.stream;
@@ -896,25 +1357,22 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     HIP_TRY(hipMemset(s->d_overflow_seq, 0xFF, sizeof(unsigned long long)));
 
     // render targets; Buffer::new / Scene::new zero-fill them (shader.rs:46-47, scene.rs:71)
-    if ((st = dev_alloc(&s->d_z, npx))) return st;
-    if ((st = dev_alloc(&s->d_shadow, npx))) return st;
-    HIP_TRY(hipMemset(s->d_z, 0, npx * 4));
-    HIP_TRY(hipMemset(s->d_shadow, 0, npx * 4));
-    if ((st = dev_alloc(&s->d_zclean, (size_t)s->n_tiles))) return st;
-    HIP_TRY(hipMemset(s->d_zclean, 0, (size_t)s->n_tiles * 4));
-    if (o.frame_buffer_device) {
-        s->d_fb = (uint8_t *)o.frame_buffer_device;
-    } else {
-        if ((st = dev_alloc(&s->d_fb_own, npx * 3))) return st;
-        HIP_TRY(hipMemset(s->d_fb_own, 0, npx * 3));
-        s->d_fb = s->d_fb_own;
+    s->slots.resize(1);
+    {
+        tr_scene::FrameSlot &fs = s->slots[0];
+        if ((st = dev_alloc(&fs.z, npx))) return st;
+        if ((st = dev_alloc(&fs.shadow, npx))) return st;
+        HIP_TRY(hipMemset(fs.z, 0, npx * 4));
+        HIP_TRY(hipMemset(fs.shadow, 0, npx * 4));
+        if ((st = dev_alloc(&fs.zclean, (size_t)s->n_tiles))) return st;
+        HIP_TRY(hipMemset(fs.zclean, 0, (size_t)s->n_tiles * 4));
     }
     if (o.flags & TR_OPT_WINNER_TAP) {
         if ((st = dev_alloc(&s->d_winner, npx))) return st;
         HIP_TRY(hipMemset(s->d_winner, 0xFF, npx * 4));
     }
-    if ((st = select_fb_flags(s))) return st;
-    if (s->d_fb == s->d_fb_own)  // zero-filled just now, winner tap at "no fragment": every tile is clean
+    if ((st = use_slot(s, 0, (uint8_t *)o.frame_buffer_device))) return st;
+    if (s->d_fb == s->slots[0].fb)  // zero-filled just now, winner tap at "no fragment": every tile is clean
         HIP_TRY(hipMemsetAsync(s->d_fbclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
     if (o.flags & TR_OPT_TILE_STAMPS) {
         if ((st = dev_alloc(&s->d_stamps, (size_t)s->n_tiles_full * 8))) return st;
@@ -1110,7 +1568,39 @@ int tr_scene_render(tr_scene *s)
     s->last.z_fb_cleared = s->z_fb_cleared;
     s->last.shadow_cleared = s->shadow_cleared;
     s->last.valid = true;
+    s->last_was_group = false;
     return render_frame(s);
+}
+
+int tr_scene_render_frames(tr_scene *s, uint32_t n_frames, const tr_frame_params *frames, void *const *frame_buffers_device)
+{
+    if (!s || (n_frames && !frames)) return tr::fail(TR_E_INVALID, "null argument");
+    if (n_frames == 0) return TR_OK;
+    if (frame_buffers_device)
+        for (uint32_t i = 0; i < n_frames; i++)
+            if (!frame_buffers_device[i]) return tr::fail(TR_E_INVALID, "null frame buffer in the list");
+    HIP_TRY(hipSetDevice(s->device));
+    return render_frames(s, n_frames, frames, frame_buffers_device);
+}
+
+int tr_scene_frames_per_launch(tr_scene *s) { return s ? (int)group_size(s) : tr::fail(TR_E_INVALID, "null scene"); }
+
+int tr_scene_frames_kept(tr_scene *s)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    return s->last_was_group ? (int)s->tail.params.size() : 0;
+}
+
+int tr_scene_select_frame(tr_scene *s, uint32_t back)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    if (!s->last_was_group || back >= s->tail.params.size())
+        return tr::fail(TR_E_INVALID, "tr_scene_select_frame: no such frame (tr_scene_frames_kept tells how many the last tr_scene_render_frames left)");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t k = s->tail.params.size() - 1u - back;
+    const tr_frame_params &q = s->tail.params[k];
+    memcpy(s->light, q.light, 12); memcpy(s->from, q.look_from, 12); memcpy(s->at, q.look_at, 12); memcpy(s->up, q.up, 12);
+    return use_slot(s, s->tail.slot[k], s->tail.fbs.empty() ? nullptr : (uint8_t *)s->tail.fbs[k]);
 }
 
 int tr_scene_flush(tr_scene *s)
@@ -1132,18 +1622,7 @@ int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
     HIP_TRY(hipSetDevice(s->device));
-    if (frame_buffer_device) {
-        s->d_fb = (uint8_t *)frame_buffer_device;
-        return select_fb_flags(s);
-    }
-    if (!s->d_fb_own) {
-        const size_t n = (size_t)s->width * s->height * 3;
-        int st = dev_alloc(&s->d_fb_own, n);
-        if (st) return st;
-        HIP_TRY(hipMemsetAsync(s->d_fb_own, 0, n, s->stream));
-    }
-    s->d_fb = s->d_fb_own;
-    return select_fb_flags(s);
+    return use_slot(s, s->cur_slot, (uint8_t *)frame_buffer_device);
 }
 
 int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1)
@@ -1295,6 +1774,7 @@ int tr_scene_profile_enable(tr_scene *s, int on)
     if (on) {
         memset(s->prof_ms, 0, sizeof s->prof_ms);
         memset(s->prof_n, 0, sizeof s->prof_n);
+        memset(s->prof_frames, 0, sizeof s->prof_frames);
         s->frame_intervals_us.clear();
     }
     return TR_OK;
@@ -1317,6 +1797,7 @@ int tr_scene_profile_read(tr_scene *s, tr_kernel_time *out, int cap)
         strncpy(out[n].name, kKernelNames[k], sizeof out[n].name - 1);
         out[n].launches = s->prof_n[k];
         out[n].total_ms = s->prof_ms[k];
+        out[n].frames = s->prof_frames[k];
         n++;
     }
     return n;

@@ -38,7 +38,7 @@ class Scene:
 
     def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
                  winner_tap=False, tile_stamps=False, band_rows=None, stream=None, frame_buffer_device=None,
-                 bin_capacity=0, tile_waves=0, tile_mode=0):
+                 bin_capacity=0, tile_waves=0, tile_mode=0, frames_per_launch=0):
         L = load_library()
         self.width, self.height = int(width), int(height)
         keep = []
@@ -61,6 +61,7 @@ class Scene:
         o.bin_capacity = int(bin_capacity)
         o.tile_waves = int(tile_waves)
         o.tile_mode = int(tile_mode)
+        o.frames_per_launch = int(frames_per_launch)
         h = C.c_void_p()
         self._h = None
         self._pinned = []
@@ -95,6 +96,33 @@ class Scene:
 
     def render(self):
         check(load_library().tr_scene_render(self._h))
+
+    def render_frames(self, frames, frame_buffers_device=None):
+        """tr_scene_render_frames: `frames` is an [n, 12] float32 array (or a list of (light, look_from,
+        look_at, up) tuples): per frame light direction, look_from, look_at, up.  Frame i is what
+        clear(); set_light_direction; set_camera; render() produces; the frames of a group are rendered by
+        one launch per kernel.  frame_buffers_device: optional list of n device pointers (colour targets)."""
+        if not isinstance(frames, np.ndarray):
+            frames = np.asarray([np.concatenate([np.asarray(v, np.float32).reshape(3) for v in f]) for f in frames],
+                                np.float32)
+        frames = np.ascontiguousarray(frames, np.float32).reshape(-1, 12)
+        fbs = None
+        if frame_buffers_device is not None:
+            if len(frame_buffers_device) != len(frames):
+                raise ValueError("one frame buffer per frame")
+            fbs = (C.c_void_p * len(frames))(*[int(q) for q in frame_buffers_device])
+        check(load_library().tr_scene_render_frames(self._h, len(frames), frames.ctypes.data, fbs))
+
+    @property
+    def frames_per_launch(self):
+        return check(load_library().tr_scene_frames_per_launch(self._h))
+
+    def frames_kept(self):
+        return check(load_library().tr_scene_frames_kept(self._h))
+
+    def select_frame(self, back):
+        """Makes the frame `back` frames before the last one of the last render_frames call current."""
+        check(load_library().tr_scene_select_frame(self._h, int(back)))
 
     def _image(self, fn, strict):
         out = np.empty((self.height, self.width, 3), np.uint8)
@@ -175,7 +203,8 @@ class Scene:
     def profile_read(self):
         buf = (_lib.KernelTime * 16)()
         n = check(load_library().tr_scene_profile_read(self._h, buf, 16))
-        return {buf[i].name.decode(): {"launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms)}
+        return {buf[i].name.decode(): {"launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms),
+                                       "frames": int(buf[i].frames)}
                 for i in range(n)}
 
 
