@@ -20,14 +20,15 @@ rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- p
     > "$out/bench_under_rocprof.log" 2> "$out/trace.err" || exit 1
 tail -n 1 "$out/bench_under_rocprof.log"
 
+# (frames: multiples of the workload's frames per launch -- 4, 16, 8, 4, 4, 4 -- so that every launch is a full group)
 # tag            size pipeline frames model        grid
 workloads=(
- "headline       4096 phong    20     diablo       1"
- "cfg0           800  default  20     african_head 1"
- "cfg1           2048 phong    20     diablo       1"
- "cfg2           4096 darboux  20     diablo       1"
- "cfg3           4096 shadow   20     diablo       1"
- "cfg4           8192 specular 6      diablo       8"
+ "headline       4096 phong    32     diablo       1"
+ "cfg0           800  default  64     african_head 1"
+ "cfg1           2048 phong    32     diablo       1"
+ "cfg2           4096 darboux  32     diablo       1"
+ "cfg3           4096 shadow   32     diablo       1"
+ "cfg4           8192 specular 8      diablo       8"
 )
 for w in "${workloads[@]}"; do
   set -- $w
@@ -41,7 +42,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYC
            "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-48)
   echo "== pmc $set"
-  rocprofv3 --pmc $set --kernel-trace -d "$out/sq_$n" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 12 \
+  rocprofv3 --pmc $set --kernel-trace -d "$out/sq_$n" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 32 \
       > "$out/sq_$n.log" 2>&1 || echo "counter set refused: $set"
 done
 find "$out" -name "*.csv" | wc -l

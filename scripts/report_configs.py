@@ -8,14 +8,14 @@ CONFIGS = [
     ("configs[2] diablo / darboux / 4096x4096", ["--pipeline", "darboux", "--size", "4096"]),
     ("configs[3] diablo / shadow / 4096x4096", ["--pipeline", "shadow", "--size", "4096"]),
     ("configs[4] diablo x64 grid / specular / 8192x8192 (one GPU)", ["--pipeline", "specular", "--size", "8192", "--grid", "8",
-                                                                      "--steps", "40", "--warmup", "5"]),
+                                                                      "--steps", "80", "--warmup", "8"]),
     ("metric: diablo / phong / 4096x4096", ["--pipeline", "phong", "--size", "4096"]),
 ]
 out = {}
 for name, flags in CONFIGS:
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--cpu-seconds", "3"] + flags
     if "--steps" not in flags:
-        cmd += ["--steps", "100", "--warmup", "10"]
+        cmd += ["--steps", "800", "--warmup", "64"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode or not line:
@@ -24,8 +24,9 @@ for name, flags in CONFIGS:
         continue
     j = json.loads(line[-1])
     out[name] = j
-    print("%-62s %8.1f us/frame  k_tile %s us  frac %.3f  parity %s  cpu %s" % (
-        name, j["ms_per_step"] * 1e3, j["kernel_us"].get("k_tile"), j["roofline"]["frac"], j["parity_vs_oracle"]["ok"],
+    print("%-62s %8.1f us/frame (%.1f per-frame protocol)  k_tile %s us/frame x %d  frac %.3f  parity %s  cpu %s" % (
+        name, j["ms_per_step"] * 1e3, (j.get("per_frame_protocol") or {}).get("ms_per_step", 0.0) * 1e3,
+        j["kernel_us_per_frame"].get("k_tile"), j["config"]["frames_per_launch"], j["roofline"]["frac"], j["parity_vs_oracle"]["ok"],
         j["cpu_baseline"]["sample"].split(",")[-1].strip() if j.get("cpu_baseline") else "-"), flush=True)
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "configs.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)

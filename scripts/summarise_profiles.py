@@ -57,7 +57,7 @@ shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(dst, tag + "_kernel_
 
 db = {"source_fingerprint": source_fingerprint(),
       "correction": "gfx950: FETCH_SIZE x2 (128-B requests tallied at 64 B), WRITE_SIZE as is; separate --pmc passes "
-                    "(MI355X_MICROARCH.md, HBM); means over the launches of scripts/frame_loop.py",
+                    "(MI355X_MICROARCH.md, HBM); means over the launches of scripts/frame_loop.py (a launch covers frames_per_launch frames)",
       "workloads": {}}
 rows = []
 for wtag, (workload, dom) in WORKLOADS.items():
@@ -73,8 +73,13 @@ for wtag, (workload, dom) in WORKLOADS.items():
             rows.append((wtag, k, c, v))
     kt = traffic[dom]
     fetch_kb, write_kb = kt.get("FETCH_SIZE", 0.0), kt.get("WRITE_SIZE", 0.0)
+    fpl = 1
+    for line in open(one("pmc_WRITE_SIZE_%s.log" % wtag)):
+        if line.startswith("frames "):
+            fpl = int(line.split()[3])   # "frames N frames_per_launch G" (scripts/frame_loop.py)
     db["workloads"][workload] = {
         "kernel": dom,
+        "frames_per_launch": fpl,
         "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024.0)),
         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
         "other_kernels_kb": {k: cs for k, cs in traffic.items() if k != dom},
@@ -90,4 +95,4 @@ json.dump({k: {c: round(v, 1) for c, v in cs.items()} for k, cs in sq.items() if
           open(os.path.join(dst, tag + "_pmc_sq_4096_phong.json"), "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, tag + "_bench_4096_phong.log")).read().strip().splitlines()[-1][:600])
 for w, e in db["workloads"].items():
-    print("%-50s %s %.1f MB/launch" % (w, e["kernel"], e["hbm_bytes_per_launch"] / 1e6))
+    print("%-50s %s %.1f MB/launch of %d frames" % (w, e["kernel"], e["hbm_bytes_per_launch"] / 1e6, e["frames_per_launch"]))

@@ -257,3 +257,37 @@ def test_full_size_group_equals_per_frame_path(diablo):
         assert np.array_equal(gpu.get_frame_buffer(), one.get_frame_buffer())
     gpu.close()
     one.close()
+
+
+def test_tiles_that_empty_after_an_orbit_are_cleared(diablo):
+    """An orbit leaves colour in tiles that are empty in the next view; their workgroups must store the
+    cleared colour although the tile's "already clean" flag is consulted by four waves that do not run in
+    lockstep (a wave that raised the flag before its siblings had read it left 4-228 stale pixels per frame
+    at this size).  4096^2 darboux: the frames after the orbit equal a fresh scene's frame."""
+    import tiny_renderer_amd as T
+    mesh, texs = diablo
+    W = Hh = 4096
+    fresh = T.Scene(W, Hh, mesh, texs, "darboux")
+    head = params(8, cam_step=0.0, light_step=0.0)
+    fresh.clear(), fresh.set_light_direction(head[0, 0:3]), fresh.set_camera(head[0, 3:6], head[0, 6:9], head[0, 9:12])
+    fresh.render()
+    z1, f1 = fresh.read_z_f32().view(np.uint32), fresh.get_frame_buffer()
+    fresh.close()
+    gpu = T.Scene(W, Hh, mesh, texs, "darboux")
+    for lap in range(2):
+        gpu.render_frames(params(200, cam_step=2.0 * np.pi / 200, light_step=0.0))
+        gpu.render_frames(head)
+        assert gpu.sync() == 0
+        for back in range(gpu.frames_kept()):
+            gpu.select_frame(back)
+            assert np.array_equal(gpu.read_z_f32().view(np.uint32), z1)
+            f = gpu.get_frame_buffer()
+            assert np.array_equal(f, f1), "lap %d frame -%d: %d stale pixels" % (lap, back, int((f != f1).any(-1).sum()))
+        # the per-frame path after the same orbit (its empty tiles take the same branch)
+        for i in range(0, 200, 7):
+            q = params(1, cam0=2.0 * np.pi * i / 200, light_step=0.0)[0]
+            gpu.clear(), gpu.set_light_direction(q[0:3]), gpu.set_camera(q[3:6], q[6:9], q[9:12]), gpu.render()
+        gpu.clear(), gpu.set_light_direction(head[0, 0:3]), gpu.set_camera(head[0, 3:6], head[0, 6:9], head[0, 9:12])
+        gpu.render()
+        assert np.array_equal(gpu.get_frame_buffer(), f1)
+    gpu.close()

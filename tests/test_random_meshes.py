@@ -100,6 +100,48 @@ def test_resolve_matches_serial_order_gpu(built, seed, mode):
         assert np.array_equal(g.read_shadow_f32().view(np.uint32), s.shadow_f32().view(np.uint32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("seed", range(8))
+def test_resolve_matches_serial_order_gpu_frame_groups(built, seed, mode):
+    """The same tie soups through tr_scene_render_frames: five views of a soup rendered by one launch of each
+    kernel (groups of 3 + 2), every frame against the oracle's serial loop."""
+    import tiny_renderer_amd as T
+    rng = np.random.default_rng(2000 + seed)
+    n_tri = int(rng.integers(1, 400))
+    grid = int(rng.choice([2, 3, 5, 9]))
+    pipe = ["default", "phong", "shadow", "occlusion", "darboux", "normal_map", "specular", "phong"][seed % 8]
+    W, Hh = [(96, 64), (130, 50), (257, 33), (640, 480)][seed % 4]
+    mesh, texs = soup(seed + 50, n_tri, grid)
+    views = [(ca, 0.4 + 0.3 * k) for k, ca in enumerate([0.0, 0.3, 3.14159, 0.3, 0.0])]
+    expect = []
+    for ca, la in views:
+        err, s = oracle_frame(W, Hh, mesh, texs, pipe, ca, la)
+        if err:
+            pytest.skip("the reference would panic on this soup")
+        expect.append(s)
+    p = np.zeros((len(views), 12), np.float32)
+    for k, (ca, la) in enumerate(views):
+        p[k, 0:3] = H.light(la)
+        p[k, 3:6], p[k, 6:9], p[k, 9:12] = H.camera(ca)
+    g = T.Scene(W, Hh, mesh, texs, pipe, tile_mode=mode, tile_waves=[0, 4, 8, 16][seed % 4], frames_per_launch=3)
+    g.render_frames(p)
+    assert g.frames_kept() == 3
+    exact = pipe != "specular" or bool(T.load_library().tr_specular_exact())
+    for back in range(3):
+        s = expect[len(views) - 1 - back]
+        g.select_frame(back)
+        assert np.array_equal(g.read_z_f32().view(np.uint32), s.z_f32().view(np.uint32))
+        fg, fo = g.get_frame_buffer(), s.get_frame_buffer()
+        if exact:
+            assert np.array_equal(fg, fo)
+        else:
+            assert np.abs(fg.astype(np.int32) - fo.astype(np.int32)).max() <= 1  # tolerance: 1 LSB (device powf)
+        if pipe in ("shadow", "occlusion"):
+            assert np.array_equal(g.read_shadow_f32().view(np.uint32), s.shadow_f32().view(np.uint32))
+    g.close()
+
+
 def far_soup(seed, n_tri):
     """Polygons that stress the f32 rounding of the edge functions: vertices far outside the frame
     (raster coordinates up to ~3e8, products far beyond 2^24), long slivers crossing the screen,

@@ -457,7 +457,11 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             // already holds them (it was empty the last time it was written, too: most of a frame,
             // most of the time); its z stays unwritten behind the tile's fast-clear flag (depth passes
             // write their f32::MIN)
-            if (DEPTH || a.fbclean == nullptr || a.fbclean[tile] == 0u) {
+            const bool stale = DEPTH || a.fbclean == nullptr || a.fbclean[tile] == 0u;
+            // every wave has read the flag before the first one raises it (a wave that came late would find
+            // it up and leave its share of the tile unwritten)
+            __syncthreads();
+            if (stale) {
                 write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
                                           (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
                 if (!DEPTH && tid == 0u && a.fbclean) a.fbclean[tile] = 1u;

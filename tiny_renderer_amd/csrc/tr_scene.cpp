@@ -696,11 +696,14 @@ int pass_uniforms(tr_scene *s, const PassDesc &p, DevUniforms &du)
 // waves with private columns do the least total work.  Measured on diablo / phong (k_tile us, best
 // of the six combinations per size, profiles/r02_notes.md): 512^2 24.8 (16 shared; 4 columns 129),
 // 1024^2 22.2 (16 shared), 2048^2 21.9 (8 shared), 2560^2 23.2 (8 columns), 4096^2 33.1 (4 columns).
-// `tiles_in_launch` counts the tiles of ALL the frames of a fused launch.
-void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, int &tile_waves, int &shared)
+// A fused launch (tr_scene_render_frames) fills the GPU with the tiles of ALL its frames, so its waves per
+// tile go by that total; whether its waves share a tile's bin still goes by the size of ONE frame, which is
+// what decides how unevenly the polygons fall on a tile's columns (800^2 african_head, 16 frames per launch,
+// k_tile per frame: 4 waves columns 4.6 us, 4 waves shared 3.3, 8 shared 3.6, 16 shared 4.4).
+void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, uint32_t tiles_per_frame, int &tile_waves, int &shared)
 {
     tile_waves = s->tile_waves ? (int)s->tile_waves : tiles_in_launch <= 1024u ? 16 : tiles_in_launch <= 4608u ? 8 : 4;
-    shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto(tiles_in_launch <= 2048u ? 1 : 0);
+    shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto(tiles_per_frame <= 2048u ? 1 : 0);
 }
 
 int run_pass(tr_scene *s, const PassDesc &p)
@@ -787,7 +790,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
     tr_scene::PendingTile pt;
     pt.fs = p.fs;
-    tile_layout(s, n_tiles_pass, pt.tile_waves, pt.shared);
+    tile_layout(s, n_tiles_pass, n_tiles_pass, pt.tile_waves, pt.shared);
     pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
     pt.p_seq = p_seq;
     pt.args = ta;
@@ -1045,7 +1048,7 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
         const PassDesc &pass = pd.pass[pi];
         const TileArgs &ta0 = h_tile[(size_t)pi * G];
         int tile_waves = 4, shared = 0;
-        tile_layout(s, (uint64_t)ta0.frame.ntx * ta0.frame.nty * g, tile_waves, shared);
+        tile_layout(s, (uint64_t)ta0.frame.ntx * ta0.frame.nty * g, ta0.frame.ntx * ta0.frame.nty, tile_waves, shared);
         EventPair ep = { nullptr, nullptr, pass.fs == FS_DEPTH ? K_TILE_DEPTH : K_TILE, g };
         if (s->profiling) {
             ep.a = take_event(s);
