@@ -647,6 +647,27 @@ def test_cli_writes_the_oracles_frame(synthetic, tmp_path, pipe, ext):
     assert np.array_equal(got, _oracle_frame(640, 360, mesh, texs, pipe, 0.4, -0.3))
 
 
+def test_cli_many_frames_uses_frame_groups(synthetic, tmp_path):
+    """`--frames 7` on one GPU goes through tr_scene_render_frames (camera orbiting over the frames); the
+    file written is the oracle's last frame, and the z view of the same run is the oracle's z view."""
+    from PIL import Image
+    from tiny_renderer_amd import cli
+    from oracle import oracle as O
+    mesh, texs = synthetic
+    angle = float(np.float32(0.2 + 2.0 * np.pi * 6 / 7))
+    for view in ("frame", "z"):
+        out = str(tmp_path / ("orbit_%s.png" % view))
+        assert cli.main(["--synthetic", "-s", "normal_map", "--width", "500", "--height", "300", "--frames", "7",
+                         "--camera-angle", "0.2", "--light-angle", "0.6", "--view", view, "--out", out]) == 0
+        got = np.array(Image.open(out).convert("RGB"))
+        if view == "frame":
+            assert np.array_equal(got, _oracle_frame(500, 300, mesh, texs, "normal_map", angle, 0.6))
+        else:
+            s = O.Scene(500, 300, mesh, texs, "normal_map")
+            s.clear(), s.set_light_direction(H.light(0.6)), s.set_camera(*H.camera(angle)), s.render()
+            assert np.array_equal(got, s.get_z_buffer())
+
+
 def test_cli_sharded_single_rank(synthetic, tmp_path):
     """`--gpus` code path of the CLI (ShardedScene: band scene on a torch side stream, two frame tensors,
     RCCL all-gather on a second stream) with a one-rank process group, in its own process; several

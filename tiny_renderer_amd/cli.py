@@ -123,9 +123,18 @@ def _run(args, T, scene, sharded, rank, say):
         return 0
 
     t0 = time.perf_counter()
-    for f in range(args.frames):
-        ca = np.float32(args.camera_angle + (2.0 * np.pi * f / args.frames if args.frames > 1 else 0.0))
-        la = np.float32(args.light_angle)
+    angles = [np.float32(args.camera_angle + (2.0 * np.pi * f / args.frames if args.frames > 1 else 0.0))
+              for f in range(args.frames)]
+    la = np.float32(args.light_angle)
+    if args.frames > 1 and not sharded:
+        # many frames, one GPU: the library's throughput path (the same frames, several per kernel launch)
+        p = np.zeros((args.frames, 12), np.float32)
+        p[:, 0:3] = [float(np.sin(la)), 0.0, float(np.cos(la))]
+        for f, ca in enumerate(angles):
+            p[f, 3:6], p[f, 6:9], p[f, 9:12] = [float(np.sin(ca)), 0.0, float(np.cos(ca))], [0, 0, 0], [0, 1, 0]
+        scene.render_frames(p)
+        angles = []
+    for ca in angles:
         scene.clear()                                                        # app.rs:170
         scene.set_light_direction([float(np.sin(la)), 0.0, float(np.cos(la))])   # app.rs:203-208
         scene.set_camera([float(np.sin(ca)), 0.0, float(np.cos(ca))], [0, 0, 0], [0, 1, 0])  # app.rs:200-209
