@@ -518,8 +518,8 @@ def main():
                         traffic_note = "profiles/pmc_traffic.json was collected on other source (%s)" % db.get("source_fingerprint")
                     elif abs(entry.get("frames_per_launch", 1) - frames_in_launch) > 0.05 * frames_in_launch:
                         traffic_note = "profiled with %s frames per launch" % entry.get("frames_per_launch", 1)
-                    elif entry.get("kernel") == dom:
-                        traffic = entry.get("hbm_bytes_per_launch")
+                    elif dom in entry.get("per_kernel_hbm_bytes_per_launch", {}) or entry.get("kernel") == dom:
+                        traffic = entry.get("per_kernel_hbm_bytes_per_launch", {}).get(dom, entry.get("hbm_bytes_per_launch"))
                         traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
                 except Exception as e:  # a malformed file must not take the bench down
                     traffic, traffic_note = None, "unreadable pmc_traffic.json: %s" % e

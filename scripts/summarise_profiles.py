@@ -82,6 +82,9 @@ for wtag, (workload, dom) in WORKLOADS.items():
         "frames_per_launch": fpl,
         "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024.0)),
         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+        # every tile kernel of the workload (a two-pass pipeline has two; bench.py asks for the dominant one)
+        "per_kernel_hbm_bytes_per_launch": {k: int(round((2.0 * cs.get("FETCH_SIZE", 0.0) + cs.get("WRITE_SIZE", 0.0)) * 1024.0))
+                                            for k, cs in traffic.items() if k.startswith("k_tile")},
         "other_kernels_kb": {k: cs for k, cs in traffic.items() if k != dom},
         "source": "profiles/%s_pmc_fetch_write.csv" % tag}
 with open(os.path.join(dst, tag + "_pmc_fetch_write.csv"), "w") as f:
