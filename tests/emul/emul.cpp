@@ -371,6 +371,21 @@ extern "C" void tr_emul_div(int which, const float *x, const float *d, float *ou
 }
 
 // decode_normal for two texels at once against the plain form; returns the number of differing components
+// shadow_fetch with fast-clear flags against the plain lookup in a fully materialised buffer: n lookups at
+// (x[i], y[i]); returns how many differ (value bits or error bits).
+extern "C" uint32_t tr_emul_shadow_fetch_mismatches(const float *plain, const float *stale, const uint32_t *sclean,
+                                                    uint32_t W, uint32_t H, const float *x, const float *y, uint32_t n)
+{
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t e0 = 0, e1 = 0;
+        const float a = shadow_fetch(plain, nullptr, W, H, make3(x[i], y[i], 0.0f), e0);
+        const float b = shadow_fetch(stale, sclean, W, H, make3(x[i], y[i], 0.0f), e1);
+        if (f32_bits(a) != f32_bits(b) || e0 != e1) bad++;
+    }
+    return bad;
+}
+
 extern "C" uint32_t tr_emul_decode_normal_mismatches(uint32_t first, uint32_t count)
 {
     uint32_t bad = 0;

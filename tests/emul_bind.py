@@ -22,6 +22,9 @@ def lib():
         L.tr_emul_div.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.tr_emul_decode_normal_mismatches.restype = C.c_uint32
         L.tr_emul_decode_normal_mismatches.argtypes = [C.c_uint32, C.c_uint32]
+        L.tr_emul_shadow_fetch_mismatches.restype = C.c_uint32
+        L.tr_emul_shadow_fetch_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                      C.c_void_p, C.c_void_p, C.c_uint32]
         L.tr_emul_pair_counts.restype = None
         L.tr_emul_pair_counts.argtypes = [C.POINTER(C.c_uint64)]
         L.tr_emul_powf.restype = C.c_int

@@ -154,3 +154,36 @@ def test_powf_reproduces_the_host_libm():
     got = out[::7]
     same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
     assert same.all(), list(zip(x[::7][~same][:5], y[::7][~same][:5], got[~same][:5], ref[~same][:5]))
+
+
+def test_shadow_lookup_through_fast_clear_flags_equals_plain_lookup():
+    """shadow_fetch with the shadow buffer's per-tile fast-clear flags (stale memory behind a raised flag) returns
+    what the plain lookup returns in the fully written buffer -- for every kind of index the reference's wrapping
+    u32 arithmetic (shader.rs:774-775) can produce: inside the frame, a column beyond the row (lands in a later
+    row), a row that wraps around 2^32 back into the buffer (y = k * 2^32 / W: every large f32 is such a
+    multiple), out of range (flagged), negative and NaN coordinates (cast to 0)."""
+    L = E.lib()
+    rng = np.random.default_rng(5)
+    for W, Hh in ((512, 512), (640, 100), (130, 70), (4096, 64)):
+        ntx, nty = (W + 127) // 128, (Hh + 15) // 16
+        plain = rng.standard_normal(W * Hh).astype(np.float32)
+        flags = (rng.random(ntx * nty) < 0.5).astype(np.uint32) * np.uint32(0xFFFFFFFF)
+        tile_of = (np.arange(Hh)[:, None] // 16) * ntx + (np.arange(W)[None, :] // 128)
+        clean = flags[tile_of].astype(bool).reshape(-1)
+        plain[clean] = np.float32(np.finfo(np.float32).min)          # what a clean tile logically holds
+        stale = plain.copy()
+        stale[clean] = np.float32(123.0)                              # ... and garbage where the flag is up
+        xs = [rng.uniform(-3, W + 3, 4000), rng.uniform(W, 40 * W, 2000), rng.uniform(0, W, 3000), rng.uniform(0, W, 500)]
+        ys = [rng.uniform(-3, Hh + 3, 4000), rng.uniform(0, Hh / 2, 2000),
+              (rng.integers(1, 64, 3000) * (2.0 ** 32 / W)) + rng.integers(0, Hh, 3000),   # wraps around 2^32
+              rng.uniform(Hh, 1e9, 500)]
+        x = np.concatenate(xs + [[np.nan, 0.0, -1e30, 1e30]]).astype(np.float32)
+        y = np.concatenate(ys + [[0.0, np.nan, 5.0, 1e30]]).astype(np.float32)
+        bad = L.tr_emul_shadow_fetch_mismatches(plain.ctypes.data, stale.ctypes.data, flags.ctypes.data, W, Hh,
+                                                x.ctypes.data, y.ctypes.data, len(x))
+        assert bad == 0, (W, Hh, bad)
+        # the wrapped rows really land inside the buffer for some lookups (otherwise the case proves nothing)
+        iy = np.minimum(np.round(ys[2].astype(np.float32)).astype(np.float64), 2.0 ** 32 - 1).astype(np.uint64)
+        ix = np.round(xs[2].astype(np.float32)).astype(np.uint64)
+        idx = (ix + iy * np.uint64(W)) % np.uint64(2 ** 32)
+        assert (idx < W * Hh).sum() > 100

@@ -864,7 +864,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                             v[4 * i - 12] = __uint_as_float(piece.z); v[4 * i - 11] = __uint_as_float(piece.w);
                         }
                         return fragment_color<FS>(a.u, a.tex, v, b, u_, v_, (uint32_t)px, (uint32_t)py_, z_, a.shadow,
-                                                  (uint32_t)W, (uint32_t)H, e_);
+                                                  (uint32_t)W, (uint32_t)H, e_, a.sclean);
                     };
                     if (PAIR) {
                         // both pixels through the closure together in packed arithmetic with shared

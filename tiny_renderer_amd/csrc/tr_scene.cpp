@@ -189,6 +189,7 @@ struct tr_scene {
     uint64_t observed_seq = 0;
     // The current targets (aliases: the memory belongs to the frame slots below, or to the caller)
     float *d_z = nullptr, *d_shadow = nullptr;
+    uint32_t *d_sclean = nullptr;  // the shadow buffer's fast-clear flags (n_tiles_full)
     uint8_t *d_fb = nullptr;      // where the next render writes
     // Frame slots: complete sets of render targets.  Slot 0 is what the scene is created with; the others
     // appear with the first tr_scene_render_frames, whose frame i goes to slot i % (frames per group).
@@ -198,6 +199,7 @@ struct tr_scene {
         float *z = nullptr;
         uint32_t *zclean = nullptr;
         float *shadow = nullptr;
+        uint32_t *sclean = nullptr;
         uint8_t *fb = nullptr;
     };
     std::vector<FrameSlot> slots;
@@ -354,6 +356,7 @@ int use_slot(tr_scene *s, int k, uint8_t *fb)
     s->d_z = fs.z;
     s->d_zclean = fs.zclean;
     s->d_shadow = fs.shadow;
+    s->d_sclean = fs.sclean;
     if (!fb) {
         int st = slot_own_fb(s, k, &fb);
         if (st != TR_OK) return st;
@@ -514,11 +517,23 @@ int flush_clear_shadow(tr_scene *s)
         int sp = submit_pending(s);
         if (sp != TR_OK) return sp;
     }
-    const size_t n = (size_t)s->width * s->height;
+    // a cleared shadow buffer = every tile's fast-clear flag up (lookups consult the flags; getters
+    // materialise the values first)
     Timed t(s, K_CLEAR);
-    int rc = launch_fill_u32(reinterpret_cast<uint32_t *>(s->d_shadow), TR_F32_MIN_BITS, n, s->stream);
-    if (rc) return launch_status(rc, "clear shadow");
+    HIP_TRY(hipMemsetAsync(s->d_sclean, 0xFF, (size_t)s->n_tiles_full * 4, s->stream));
     s->shadow_cleared = false;
+    return TR_OK;
+}
+
+// Gives the shadow buffer plain-memory meaning for a getter.
+int materialize_shadow(tr_scene *s)
+{
+    {
+        int sp = submit_pending(s);
+        if (sp != TR_OK) return sp;
+    }
+    int rc = launch_materialize_depth(s->d_shadow, s->d_sclean, s->frame_full, s->stream);
+    if (rc) return launch_status(rc, "k_materialize_depth");
     return TR_OK;
 }
 
@@ -781,8 +796,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.shadow = s->d_shadow;
     ta.fb = s->d_fb;
     ta.winner = s->d_winner;
-    ta.zclean = depth_pass ? nullptr : s->d_zclean;
+    ta.zclean = depth_pass ? s->d_sclean : s->d_zclean;
     ta.fbclean = depth_pass ? nullptr : s->d_fbclean;
+    ta.sclean = (p.fs == FS_SHADOW2 || p.fs == FS_OCCLUSION2) ? s->d_sclean : nullptr;
     ta.err = s->d_err;
     ta.fresh = fresh;
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
@@ -854,7 +870,11 @@ uint32_t group_size(const tr_scene *s)
     if (forced >= 1 && forced <= GROUP_MAX) return (uint32_t)forced;
     if (s->frames_per_launch) return s->frames_per_launch;
     uint32_t g = s->n_tiles ? 16384u / s->n_tiles : (uint32_t)GROUP_MAX;
-    return g < 4u ? 4u : g > (uint32_t)GROUP_MAX ? (uint32_t)GROUP_MAX : g;
+    g = g < 4u ? 4u : g > (uint32_t)GROUP_MAX ? (uint32_t)GROUP_MAX : g;
+    // the sets of bins of the groups in flight stay below 48 GiB (a 16384^2 frame: 3 GiB of bins per pass)
+    const uint64_t per_frame = (uint64_t)bin_tiles(s) * s->bin_cap * s->rec_pieces * 16ull * (uint64_t)kPipelines[s->pipeline].n_passes;
+    while (g > 1u && (uint64_t)GROUP_SETS * g * per_frame > (48ull << 30)) g--;
+    return g;
 }
 
 // Frame slots 1 .. n - 1 (slot 0 exists since tr_scene_create).  Their z memory needs no initial value:
@@ -867,13 +887,18 @@ int ensure_slots(tr_scene *s, uint32_t n)
         int st = dev_alloc(&fs.z, npx);
         if (st == TR_OK) st = dev_alloc(&fs.zclean, (size_t)s->n_tiles);
         if (st == TR_OK && kPipelines[s->pipeline].n_passes == 2) st = dev_alloc(&fs.shadow, npx);
+        if (st == TR_OK && kPipelines[s->pipeline].n_passes == 2) st = dev_alloc(&fs.sclean, (size_t)s->n_tiles_full);
         if (st != TR_OK) {
             dev_free(fs.z);
             dev_free(fs.zclean);
             dev_free(fs.shadow);
+            dev_free(fs.sclean);
             return st;
         }
-        if (!fs.shadow) fs.shadow = s->slots[0].shadow;  // never written without a depth pass
+        if (!fs.shadow) {  // never written without a depth pass
+            fs.shadow = s->slots[0].shadow;
+            fs.sclean = s->slots[0].sclean;
+        }
         s->slots.push_back(fs);
     }
     return TR_OK;
@@ -990,8 +1015,9 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             ta.shadow = slot.shadow;
             ta.fb = fb;
             ta.winner = nullptr;
-            ta.zclean = depth_pass ? nullptr : slot.zclean;
+            ta.zclean = depth_pass ? slot.sclean : slot.zclean;
             ta.fbclean = depth_pass ? nullptr : fbclean;
+            ta.sclean = (pass.fs == FS_SHADOW2 || pass.fs == FS_OCCLUSION2) ? slot.sclean : nullptr;
             ta.err = s->d_err;
             ta.fresh = 1u;  // every frame of a group starts from cleared targets
             ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
@@ -1213,7 +1239,10 @@ void destroy(tr_scene *s)
         tr_scene::FrameSlot &fs = s->slots[k];
         dev_free(fs.z);
         dev_free(fs.zclean);
-        if (k == 0 || fs.shadow != s->slots[0].shadow) dev_free(fs.shadow);
+        if (k == 0 || fs.shadow != s->slots[0].shadow) {
+            dev_free(fs.shadow);
+            dev_free(fs.sclean);
+        }
         dev_free(fs.fb);
     }
     for (tr_scene::GroupSet &g : s->grp) {
@@ -1369,6 +1398,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         HIP_TRY(hipMemset(fs.shadow, 0, npx * 4));
         if ((st = dev_alloc(&fs.zclean, (size_t)s->n_tiles))) return st;
         HIP_TRY(hipMemset(fs.zclean, 0, (size_t)s->n_tiles * 4));
+        if ((st = dev_alloc(&fs.sclean, (size_t)s->n_tiles_full))) return st;
+        HIP_TRY(hipMemset(fs.sclean, 0, (size_t)s->n_tiles_full * 4));
     }
     if (o.flags & TR_OPT_WINNER_TAP) {
         if ((st = dev_alloc(&s->d_winner, npx))) return st;
@@ -1712,6 +1743,7 @@ int tr_scene_get_shadow_buffer(tr_scene *s, uint8_t *rgb)
     int fst = sync_and_status(s);
     if (fatal(fst)) return fst;
     int st = flush_clear_shadow(s);
+    if (st == TR_OK) st = materialize_shadow(s);
     if (st != TR_OK) return st;
     return depth_view(s, fst, s->d_shadow, rgb);
 }
@@ -1733,6 +1765,7 @@ int tr_scene_read_shadow_f32(tr_scene *s, float *out)
     int fst = sync_and_status(s);
     if (fatal(fst)) return fst;
     int st = flush_clear_shadow(s);
+    if (st == TR_OK) st = materialize_shadow(s);
     if (st != TR_OK) return st;
     return finish_read_back(s, fst, out, s->d_shadow, (size_t)s->width * s->height * 4);
 }

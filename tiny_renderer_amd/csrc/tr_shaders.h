@@ -322,7 +322,10 @@ TR_HD bool project_point(const float *mat, vec3 p, vec3 &out)
 
 // (c.x.round() as u32 + (c.y.round() as u32) * width) as usize with wrapping u32 arithmetic
 // (shader.rs:774-775); out-of-range indices panic in the reference and are flagged here.
-TR_HD float shadow_fetch(const float *shadow, uint32_t W, uint32_t H, vec3 c, uint32_t &err)
+// `sclean` (may be null): the shadow buffer's fast-clear flags, one per 128x16 tile of the whole frame --
+// non-zero = every value of the tile is f32::MIN and its memory is stale (the depth pass did not write the
+// tiles it had no polygons for).  The flag of the tile the flat index falls into is consulted first.
+TR_HD float shadow_fetch(const float *shadow, const uint32_t *sclean, uint32_t W, uint32_t H, vec3 c, uint32_t &err)
 {
     uint32_t ix = f32_to_u32(roundf(c.x));
     uint32_t iy = f32_to_u32(roundf(c.y));
@@ -330,6 +333,17 @@ TR_HD float shadow_fetch(const float *shadow, uint32_t W, uint32_t H, vec3 c, ui
     if (idx >= W * H) {
         err |= DE_SHADOW_OOB;
         return bits_f32(TR_F32_MIN_BITS);
+    }
+    if (sclean) {
+        // the flat index is what counts upstream (wrapping u32 arithmetic): a column beyond the row lands in
+        // a later row, and a huge row can wrap around 2^32 into the buffer (y = 2^23 at W = 512) -- then the
+        // tile is that of the pixel the index names
+        if (ix >= W || iy >= H) {
+            iy = idx / W;
+            ix = idx - iy * W;
+        }
+        if (sclean[(iy / (uint32_t)TILE_H) * ((W + (uint32_t)TILE_W - 1u) / (uint32_t)TILE_W) + ix / (uint32_t)TILE_W] != 0u)
+            return bits_f32(TR_F32_MIN_BITS);
     }
     return shadow[idx];
 }
@@ -340,7 +354,8 @@ TR_HD float shadow_fetch(const float *shadow, uint32_t W, uint32_t H, vec3 c, ui
 template <int FS>
 TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, const float *vary,
                               vec3 bar, float uu, float vv, uint32_t x, uint32_t y, float z,
-                              const float *shadow, uint32_t W, uint32_t H, uint32_t &err)
+                              const float *shadow, uint32_t W, uint32_t H, uint32_t &err,
+                              const uint32_t *sclean = nullptr)
 {
     vec3 tl = make3(u.t_light[0], u.t_light[1], u.t_light[2]);
 
@@ -410,7 +425,7 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
             err |= DE_W_ZERO;
             return 0u;
         }
-        float sv = shadow_fetch(shadow, W, H, sc, err);
+        float sv = shadow_fetch(shadow, sclean, W, H, sc, err);
         float coef = 1.0f;
         if (sc.z + 1.0f < sv) coef = 0.3f;
         uint32_t c = fetch_texel(tex, 0, 0, uu, vv, err);
@@ -424,7 +439,7 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
             err |= DE_W_ZERO;
             return 0u;
         }
-        float fsv = shadow_fetch(shadow, W, H, fsc, err);
+        float fsv = shadow_fetch(shadow, sclean, W, H, fsc, err);
         float occ = 1.0f;
         for (int i = 0; i < 16; i++) {
             vec3 sample = add3(world, make3(u.occl_steps[3 * i], u.occl_steps[3 * i + 1],
@@ -434,7 +449,7 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
                 err |= DE_W_ZERO;
                 return 0u;
             }
-            float sv = shadow_fetch(shadow, W, H, ssc, err);
+            float sv = shadow_fetch(shadow, sclean, W, H, ssc, err);
             if (sv - 1.0f > fsv) {
                 float strength = fminf((sv - fsv) / 20.0f, 1.0f);
                 occ -= (1.0f / 16.0f) * strength;

@@ -208,6 +208,9 @@ struct TileArgs {
     // the cleared value in memory -- the tile was empty when it was last written -- so an empty tile of
     // a cleared frame has nothing to store.  Null for depth passes.
     uint32_t *fbclean;
+    // The shadow buffer's fast-clear flags (one per tile of the WHOLE frame), for the colour passes that look
+    // the shadow buffer up (shadow, occlusion); the depth pass that fills the buffer has them as its `zclean`.
+    const uint32_t *sclean;
 };
 
 }  // namespace tr
