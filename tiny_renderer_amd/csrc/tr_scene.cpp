@@ -915,6 +915,10 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
         HIP_TRY(hipEventCreateWithFlags(&gs.ev_tile, hipEventDisableTiming));
     }
     int st = TR_OK;
+    if ((gs.frames < frames || gs.bin_cap != s->bin_cap) && gs.in_flight) {
+        HIP_TRY(hipEventSynchronize(gs.ev_tile));  // its memory is about to be replaced
+        gs.in_flight = false;
+    }
     if (gs.frames < frames) {
         dev_free(gs.count);
         dev_free(gs.order);
@@ -1100,9 +1104,16 @@ int submit_groups(tr_scene *s, bool all)
     while (s->group_submitted < s->group_seq) {
         tr_scene::GroupSet &gs = s->grp[s->group_submitted % GROUP_SETS];
         const bool ready = hipEventQuery(gs.ev_setup) == hipSuccess;
-        // two groups held back at most: the next setup needs the set of group_seq - GROUP_SETS, whose tile
-        // kernels must be on the stream by then
-        if (!ready && !all && s->group_seq - s->group_submitted <= 2) break;
+        if (!ready && !all) {
+            // a main stream that has run dry (the first group of a call, typically) gets the group at once, behind
+            // a wait: an idle GPU loses nothing to the packet, and a call of a few frames is mostly start-up
+            // (20 frames at 4096^2: 40.3 -> 33 us per frame)
+            const bool idle = s->group_submitted == 0 ||
+                              hipEventQuery(s->grp[(s->group_submitted - 1) % GROUP_SETS].ev_tile) == hipSuccess;
+            // otherwise two groups are held back at most: the next setup needs the set of group_seq - GROUP_SETS,
+            // whose tile kernels must be on the stream by then
+            if (!idle && s->group_seq - s->group_submitted <= 2) break;
+        }
         int st = submit_group_tiles(s, !ready);
         if (st != TR_OK && status == TR_OK) status = st;
     }
@@ -1127,6 +1138,9 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     if (st != TR_OK) return st;
     const uint32_t G = group_size(s);
     if ((st = ensure_slots(s, G < n ? G : n)) != TR_OK) return st;
+    // all the sets of groups in flight now (allocations of a few hundred MiB each: not in the middle of a call)
+    for (int k = 0; k < GROUP_SETS && !s->d_winner; k++)
+        if ((st = ensure_group_set(s, s->grp[k], G)) != TR_OK) return st;
     s->host_status = TR_OK;
     const uint64_t first_seq = s->pass_seq;
     const uint32_t np = (uint32_t)kPipelines[s->pipeline].n_passes;
