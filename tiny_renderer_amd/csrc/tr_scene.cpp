@@ -1161,8 +1161,15 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
             st = run_group(s, p + i0, fbs ? fbs + i0 : nullptr, slot_of, g);
             if (st == TR_OK) st = submit_groups(s, false);
             if (st != TR_OK) {
-                (void)submit_groups(s, true);
+                // (a singular camera in frame i0 .. i0 + g - 1, or the device refused a launch): the groups before are
+                // on their way, this one and the rest are not rendered; nothing of the call can be selected
+                (void)fence_setup_stream(s);
                 s->host_status = st;
+                s->tail.params.clear();
+                s->tail.fbs.clear();
+                s->tail.slot.clear();
+                s->last_was_group = true;
+                s->last.valid = false;
                 return st;
             }
         }
