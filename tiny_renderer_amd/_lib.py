@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIB = os.environ.get("TR_LIBRARY") or os.path.join(_HERE, "lib", "libtiny_renderer.so")
+_LIB = (os.environ.get("TR_LIBRARY") and os.path.abspath(os.environ["TR_LIBRARY"])) or os.path.join(_HERE, "lib", "libtiny_renderer.so")
 
 TR_OK = 0
 TR_E_INVALID = -1

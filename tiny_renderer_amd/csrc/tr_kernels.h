@@ -28,7 +28,6 @@ int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkIte
 // SHARED parameter; falls back to columns when n_polygons or a.bin_cap exceed the key's fields).
 int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
                 uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
-int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
                     uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st);

@@ -369,10 +369,13 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 #ifndef TR_WPE_NORMAL_MAP
 #define TR_WPE_NORMAL_MAP 6
 #endif
+#ifndef TR_WPE_LIGHT
+#define TR_WPE_LIGHT 6
+#endif
 constexpr int tile_waves_per_eu(int fs, int tile_waves)
 {
     const int want = fs == FS_DARBOUX ? TR_WPE_DARBOUX : fs == FS_SPECULAR ? TR_WPE_SPECULAR
-                     : fs == FS_NORMAL_MAP ? TR_WPE_NORMAL_MAP : 6;
+                     : fs == FS_NORMAL_MAP ? TR_WPE_NORMAL_MAP : TR_WPE_LIGHT;
     // sixteen waves per tile: a workgroup brings four waves to every SIMD, so 8 (two workgroups per
     // CU) or 4 (one) are the only useful budgets
     if (tile_waves == 16) return want >= 6 ? 8 : 4;
@@ -996,14 +999,6 @@ __global__ __launch_bounds__(256) void k_materialize_depth(float *zbuf, uint32_t
     if (threadIdx.x == 0u) zclean[t] = 0u;
 }
 
-// Scene::clear materialised (scene.rs:128-137) for the cases the render cannot fold it in.
-__global__ __launch_bounds__(256) void k_fill_u32(uint32_t *dst, uint32_t value, size_t n)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = value;
-}
-
-// get_z_buffer / get_shadow_buffer (scene.rs:101-125): `v as u8` replicated to rgb, flipped.
 __global__ __launch_bounds__(256) void k_depth_view(const float *src, uint8_t *dst, uint32_t W, uint32_t H)
 {
     const size_t n = (size_t)W * H;
@@ -1249,16 +1244,6 @@ int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t 
         if (tile_waves == 4) return launch_tile_waves<4, false>(fs, a, n_tiles, group, n_frames, st, start, done);
     }
     return (int)hipErrorInvalidValue;
-}
-
-int launch_fill_u32(uint32_t *dst, uint32_t value, size_t n, hipStream_t st)
-{
-    if (n == 0) return 0;
-    size_t blocks = (n + 255u) / 256u;
-    if (blocks > 8192u) blocks = 8192u;
-    hipLaunchKernelGGL(k_fill_u32, dim3((uint32_t)blocks), dim3(256), 0, st, dst, value, n);
-    TR_LAUNCH_CHECK();
-    return 0;
 }
 
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st)
