@@ -63,6 +63,7 @@ typedef struct tr_image_rgb8 {
 
 #define TR_OPT_WINNER_TAP 0x1u /* keep a per-pixel winning-polygon index (parity tap) */
 #define TR_OPT_TILE_STAMPS 0x2u /* diagnostic: record per-tile start/end clocks of the last pass */
+#define TR_OPT_NO_AUTO_GROUP 0x4u /* tr_scene_render submits every frame on its own (see tr_scene_render) */
 
 typedef struct tr_options {
     uint32_t struct_size;      /* = sizeof(tr_options) */
@@ -103,7 +104,13 @@ int tr_scene_clear(tr_scene *s);                                  /* scene.rs:12
 int tr_scene_set_light_direction(tr_scene *s, const float v[3]); /* scene.rs:140-142 */
 int tr_scene_set_camera(tr_scene *s, const float look_from[3], const float look_at[3],
                         const float up[3]);                       /* scene.rs:145-149 */
-int tr_scene_render(tr_scene *s);                                 /* scene.rs:151-268 (async) */
+/* scene.rs:151-268.  Asynchronous.  On the library's own stream a render that follows a clear may be held back
+ * on the host until a few such frames have been issued (tr_scene_frames_per_launch) and is then rendered
+ * together with them by fused kernel launches (as tr_scene_render_frames does; only the last frame's targets
+ * are the scene's, which is all the per-frame protocol lets anybody see).  Every getter, tr_scene_sync,
+ * tr_scene_flush and tr_scene_get_frame_buffer_async submit what is held back first, so a frame that is read
+ * right after its render goes to the device alone, at once. */
+int tr_scene_render(tr_scene *s);
 
 /* Many frames per call -- the throughput path (nothing of the kind upstream, whose caller renders one frame per
  * window refresh, app.rs:170-213).  Frame i of the call is exactly what

@@ -359,3 +359,122 @@ def test_group_then_callers_buffer_for_single_frames(small_synthetic):
     gpu.clear(), gpu.render()
     assert np.array_equal(gpu.get_frame_buffer(), want[0])
     gpu.close()
+
+
+# ---- automatic frame groups: the per-frame calls, held back and fused by the library ------------------------
+
+def _per_frame(s, q, clear=True):
+    if clear:
+        s.clear()
+    s.set_light_direction(q[0:3])
+    s.set_camera(q[3:6], q[6:9], q[9:12])
+    s.render()
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow", "darboux"])
+def test_auto_groups_read_after_k_frames(small_synthetic, pipe):
+    """clear -> set_* -> render, k times without a read, then a getter: the frame returned is the oracle's k-th
+    frame whatever k is (one frame alone takes the ordinary path, 2..G a partial group, more than G full groups
+    plus a remainder), z and shadow buffer too; an accumulating render and a pending clear survive the hold-back."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 352, 224
+    p = params(48, cam_step=0.29)
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, frames_per_launch=4)
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    i = 0
+    for k in (1, 2, 3, 4, 5, 7, 9, 1, 6):
+        for _ in range(k):
+            _per_frame(gpu, p[i]); _per_frame(cpu, p[i])
+            i += 1
+        assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer()), "after %d frames" % k
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
+        if pipe == "shadow":
+            assert np.array_equal(gpu.read_shadow_f32().view(np.uint32), cpu.shadow_f32().view(np.uint32))
+    # held-back frames, then a render WITHOUT clear (accumulates onto the last of them), then a clear that stays pending
+    for _ in range(2):
+        _per_frame(gpu, p[i]); _per_frame(cpu, p[i]); i += 1
+    _per_frame(gpu, p[i], clear=False); _per_frame(cpu, p[i], clear=False); i += 1
+    _per_frame(gpu, p[i]); _per_frame(cpu, p[i]); i += 1
+    gpu.clear(); cpu.clear()
+    assert not gpu.get_frame_buffer().any() and not cpu.get_frame_buffer().any()   # the clear, materialised
+    _per_frame(gpu, p[i], clear=False); _per_frame(cpu, p[i], clear=False)
+    assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer())
+    gpu.close()
+
+
+def test_auto_groups_equal_the_unfused_path_and_can_be_switched_off(synthetic):
+    import tiny_renderer_amd as T
+    mesh, texs = synthetic
+    W, Hh, n = 640, 400, 11
+    p = params(n)
+    frames = []
+    for auto in (True, False):
+        s = T.Scene(W, Hh, mesh, texs, "normal_map", auto_group=auto)
+        s.profile_enable(True)
+        for q in p:
+            _per_frame(s, q)
+        prof = s.profile_read()
+        s.profile_enable(False)
+        assert prof["k_tile"]["frames"] == n
+        if auto:
+            assert prof["k_tile"]["launches"] < n       # fused launches ...
+        else:
+            assert prof["k_tile"]["launches"] == n      # ... or one per frame
+        frames.append((s.get_frame_buffer(), s.read_z_f32().view(np.uint32).copy()))
+        s.close()
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+    want = oracle_frames(W, Hh, mesh, texs, "normal_map", p[-1:])[0]
+    assert np.array_equal(frames[0][0], want[0]) and np.array_equal(frames[0][1], want[1])
+
+
+def test_auto_groups_with_alternating_callers_buffers_and_async_reads(small_synthetic):
+    """A caller on the library's own stream that alternates two colour buffers (tr_scene_set_frame_buffer_device)
+    finds the last two frames in them after a sync although the frames were fused; asynchronous read-backs queued
+    between the renders each get their own frame."""
+    import torch
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W, Hh, n = 320, 192, 9
+    p = params(n)
+    want = oracle_frames(W, Hh, mesh, texs, "phong", p)
+    bufs = [torch.full((Hh * W * 3,), 5, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", frames_per_launch=4)
+    for i in range(n):
+        gpu.set_frame_buffer_device(bufs[i % 2].data_ptr())
+        _per_frame(gpu, p[i])
+    assert gpu.sync() == 0
+    torch.cuda.synchronize()
+    for i in (n - 2, n - 1):
+        assert np.array_equal(bufs[i % 2].cpu().numpy().reshape(Hh, W, 3), want[i][0]), "frame %d" % i
+    gpu.set_frame_buffer_device(None)
+    pinned = [gpu.pinned_frame() for _ in range(n)]
+    for i in range(n):
+        _per_frame(gpu, p[i])
+        if i % 3 != 1:
+            gpu.get_frame_buffer_async(pinned[i])
+    assert gpu.sync() == 0
+    for i in range(n):
+        if i % 3 != 1:
+            assert np.array_equal(pinned[i], want[i][0]), "read-back of frame %d" % i
+    gpu.close()
+
+
+def test_auto_groups_bin_overflow_and_teardown(synthetic):
+    """Bins too small for frames that were fused behind the caller's back: the getter still returns the right
+    frame (the last render is replayed); a scene destroyed with frames held back renders them on the way out."""
+    import tiny_renderer_amd as T
+    mesh, texs = synthetic
+    W, Hh = 256, 256
+    p = params(7)
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", bin_capacity=64, frames_per_launch=4)
+    for q in p:
+        _per_frame(gpu, q)
+    want = oracle_frames(W, Hh, mesh, texs, "phong", p[-1:])[0]
+    assert np.array_equal(gpu.read_z_f32().view(np.uint32), want[1])
+    assert np.array_equal(gpu.get_frame_buffer(), want[0])
+    for q in p[:3]:
+        _per_frame(gpu, q)
+    gpu.close()   # three frames still on the host

@@ -23,6 +23,7 @@ TR_EXCHANGE_HANDLE_BYTES = 256
 
 TR_OPT_WINNER_TAP = 0x1
 TR_OPT_TILE_STAMPS = 0x2
+TR_OPT_NO_AUTO_GROUP = 0x4
 
 
 class TinyRendererError(RuntimeError):

@@ -218,6 +218,15 @@ struct tr_scene {
     } grp[GROUP_SETS];
     uint64_t group_seq = 0;       // groups whose setup has been queued
     uint64_t group_submitted = 0; // groups whose tile kernels have been queued (<= group_seq)
+    bool groups_unfenced = false; // group tile kernels were queued since the setup stream was last ordered behind them
+    // Automatic frame groups: cleared frames rendered through the per-frame calls on the library's own stream
+    // are held back until a group is full (or anything needs them) and then rendered by fused launches.
+    struct DeferredFrame {
+        tr_frame_params p;
+        uint8_t *fb;  // the colour target that was current at its render()
+    };
+    std::vector<DeferredFrame> deferred;
+    bool auto_group = true;
     // The frames of the last tr_scene_render_frames call that still exist (the last `frames per group` of
     // them): what tr_scene_select_frame chooses from, and what is rendered again after a bin overflow.
     struct {
@@ -451,9 +460,9 @@ int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
     return status;
 }
 
-// Puts ALL pending tile kernels on the main stream: one wait for the setup stream (it is in order,
-// so the newest pass's event covers the older ones), then the kernels back to back.
-int submit_pending(tr_scene *s)
+// Puts ALL pending per-frame tile kernels on the main stream: one wait for the setup stream (it is in
+// order, so the newest pass's event covers the older ones), then the kernels back to back.
+int submit_pending_tiles(tr_scene *s)
 {
     if (s->pending.empty()) return TR_OK;
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[s->pending.back().p_seq % RING], 0));
@@ -485,6 +494,20 @@ int submit_ready(tr_scene *s)
         if (st != TR_OK && status == TR_OK) status = st;
     }
     return status;
+}
+
+int flush_deferred(tr_scene *s, bool hold_back);
+int finish_groups(tr_scene *s);
+
+// Everything the scene has been asked to render goes to the device: frames `render` has held back to fuse
+// them (below, "Automatic frame groups"), per-frame tile kernels waiting for their setup, groups' tile
+// kernels.  Runs before every use of the main stream and before anything waits for the scene.
+int submit_pending(tr_scene *s)
+{
+    int st = flush_deferred(s, false);
+    int st2 = submit_pending_tiles(s);
+    int st3 = finish_groups(s);
+    return st != TR_OK ? st : st2 != TR_OK ? st2 : st3;
 }
 
 // Materialise a pending clear of the z / frame buffers (and winner tap).
@@ -726,6 +749,11 @@ int run_pass(tr_scene *s, const PassDesc &p)
     DevUniforms du;
     int st = pass_uniforms(s, p, du);
     if (st != TR_OK) return st;
+    // a per-frame pass after frame groups: their tile kernels first (it may render onto their targets)
+    if (s->group_submitted < s->group_seq || s->groups_unfenced) {
+        st = finish_groups(s);
+        if (st != TR_OK) return st;
+    }
 
     const bool depth_pass = (p.fs == FS_DEPTH);
     // Which targets does this pass write, and are they logically cleared?
@@ -817,7 +845,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     // it: from here on the pass counts as handed on, see recover_from_overflow)
     if (!s->own_stream) {
         s->observed_seq = s->pass_seq;
-        return submit_pending(s);
+        return submit_pending_tiles(s);
     }
     // the library's own stream: see "Handing tile kernels to the main stream" above
     int status = TR_OK;
@@ -1089,6 +1117,7 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
         if (s->profiling) s->events.push_back(ep);
     }
     HIP_TRY(hipEventRecord(gs.ev_tile, s->stream));
+    s->groups_unfenced = true;
     if (!s->own_stream) s->observed_seq = s->pass_seq;  // a caller's stream: handed on (see recover_from_overflow)
     return TR_OK;
 }
@@ -1120,15 +1149,99 @@ int submit_groups(tr_scene *s, bool all)
     return status;
 }
 
-// Groups are done: later per-frame passes set up on the setup stream reuse the per-frame bins, which the tile
-// kernels queued so far may still read -- order the setup stream behind the main stream once.
-int fence_setup_stream(tr_scene *s)
+// All groups' tile kernels to the main stream, and -- once per batch of groups -- the setup stream ordered
+// behind them: per-frame passes set up later reuse the per-frame bins and counters, which tile kernels queued
+// so far may still read.
+int finish_groups(tr_scene *s)
 {
     int st = submit_groups(s, true);
     if (st != TR_OK) return st;
-    const tr_scene::GroupSet &gs = s->grp[(s->group_seq + GROUP_SETS - 1) % GROUP_SETS];
-    if (gs.in_flight) HIP_TRY(hipStreamWaitEvent(s->setup_stream, gs.ev_tile, 0));
+    if (s->groups_unfenced) {
+        const tr_scene::GroupSet &gs = s->grp[(s->group_submitted + GROUP_SETS - 1) % GROUP_SETS];
+        HIP_TRY(hipStreamWaitEvent(s->setup_stream, gs.ev_tile, 0));
+        s->groups_unfenced = false;
+    }
     return TR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Automatic frame groups
+// ---------------------------------------------------------------------------------------------
+// The reference's caller renders frame after frame through clear -> set_* -> render (app.rs:170-213).  On the
+// library's own stream nobody can observe a frame before the next getter / sync / flush, so `render` of a
+// CLEARED frame only records the frame (light, camera, colour target) and returns; when a group's worth of
+// frames has been recorded -- or anything needs them -- they are rendered together by the fused launches of
+// run_group: the last one into the scene's current targets, the ones before it (which the per-frame protocol
+// overwrites unobserved) into other frame slots.  A frame that must be seen alone (a getter right after it)
+// goes through the ordinary per-frame path, so an interactive loop is what it was; a loop that keeps
+// rendering gets the group rate without calling tr_scene_render_frames (4096^2 phong: 36 -> 30 us per frame).
+// Not on a caller's stream (its next operation may consume the frame), not for accumulating renders, not with
+// the winner tap or tile stamps (single buffers).  TR_OPT_NO_AUTO_GROUP / TR_AUTO_GROUP=0 turn it off.
+bool frame_is_groupable(const tr_scene *s)
+{
+    static const int env_on = getenv("TR_AUTO_GROUP") ? atoi(getenv("TR_AUTO_GROUP")) : 1;
+    return env_on && s->auto_group && s->own_stream && !s->d_winner && !s->d_stamps && s->z_fb_cleared &&
+           (kPipelines[s->pipeline].n_passes == 1 || s->shadow_cleared) && group_size(s) > 1u;
+}
+
+// Renders the frames `render` has held back.  hold_back: a group has just filled up inside a running loop --
+// its tile kernels may wait on the host until their setup has completed (submit_groups); otherwise everything
+// is handed to the device now.
+int flush_deferred(tr_scene *s, bool hold_back)
+{
+    if (s->deferred.empty()) return TR_OK;
+    std::vector<tr_scene::DeferredFrame> fr;
+    fr.swap(s->deferred);
+    const uint32_t g = (uint32_t)fr.size();
+    int st = TR_OK;
+    if (g == 1u) {
+        // alone: the ordinary path, from the state the frame was recorded in
+        float keep[12];
+        memcpy(keep, s->light, 12); memcpy(keep + 3, s->from, 12); memcpy(keep + 6, s->at, 12); memcpy(keep + 9, s->up, 12);
+        const bool z_now = s->z_fb_cleared, sh_now = s->shadow_cleared;
+        uint8_t *fb_now = s->d_fb;
+        const tr_frame_params &q = fr[0].p;
+        memcpy(s->light, q.light, 12); memcpy(s->from, q.look_from, 12); memcpy(s->at, q.look_at, 12); memcpy(s->up, q.up, 12);
+        s->z_fb_cleared = s->shadow_cleared = true;
+        if (fr[0].fb != fb_now) st = use_slot(s, s->cur_slot, fr[0].fb == s->slots[(size_t)s->cur_slot].fb ? nullptr : fr[0].fb);
+        if (st == TR_OK) st = render_frame(s);
+        if (fr[0].fb != fb_now) {
+            int st2 = use_slot(s, s->cur_slot, fb_now == s->slots[(size_t)s->cur_slot].fb ? nullptr : fb_now);
+            if (st == TR_OK) st = st2;
+        }
+        // a clear() issued after that render stays pending
+        s->z_fb_cleared = s->z_fb_cleared || z_now;
+        s->shadow_cleared = s->shadow_cleared || sh_now;
+        memcpy(s->light, keep, 12); memcpy(s->from, keep + 3, 12); memcpy(s->at, keep + 6, 12); memcpy(s->up, keep + 9, 12);
+        return st;
+    }
+    // per-frame tile kernels issued before these frames go first (same targets)
+    st = submit_pending_tiles(s);
+    if (st != TR_OK) return st;
+    const uint32_t G = group_size(s);
+    if ((st = ensure_slots(s, G < g ? g : G)) != TR_OK) return st;
+    tr_frame_params params[GROUP_MAX];
+    void *fbs[GROUP_MAX];
+    int slot_of[GROUP_MAX];
+    int next_slot = 0;
+    for (uint32_t j = 0; j < g; j++) {
+        params[j] = fr[j].p;
+        if (j + 1 == g) {
+            slot_of[j] = s->cur_slot;       // the frame the caller will see: the current targets
+            fbs[j] = fr[j].fb == s->slots[(size_t)s->cur_slot].fb ? nullptr : fr[j].fb;
+        } else {
+            if (next_slot == s->cur_slot) next_slot++;
+            slot_of[j] = next_slot++;
+            // its colour goes where the caller pointed render() unless a later frame of the group goes there
+            // too (then nobody can see it: the slot's own buffer)
+            bool overwritten = false;
+            for (uint32_t k = j + 1; k < g; k++) overwritten = overwritten || fr[k].fb == fr[j].fb;
+            fbs[j] = overwritten ? nullptr : fr[j].fb;
+        }
+    }
+    st = run_group(s, params, fbs, slot_of, g);
+    if (st == TR_OK) st = hold_back ? submit_groups(s, false) : finish_groups(s);
+    return st;
 }
 
 // n cleared frames, frame i into slot i % G; afterwards the last one is the scene's current frame.
@@ -1163,7 +1276,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
             if (st != TR_OK) {
                 // (a singular camera in frame i0 .. i0 + g - 1, or the device refused a launch): the groups before are
                 // on their way, this one and the rest are not rendered; nothing of the call can be selected
-                (void)fence_setup_stream(s);
+                (void)finish_groups(s);
                 s->host_status = st;
                 s->tail.params.clear();
                 s->tail.fbs.clear();
@@ -1173,7 +1286,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
                 return st;
             }
         }
-        if ((st = fence_setup_stream(s)) != TR_OK) return st;
+        if ((st = finish_groups(s)) != TR_OK) return st;
         // the scene now stands where the per-frame calls would have left it
         const tr_frame_params &l = p[n - 1];
         memcpy(s->light, l.light, 12); memcpy(s->from, l.look_from, 12); memcpy(s->at, l.look_at, 12); memcpy(s->up, l.up, 12);
@@ -1211,7 +1324,7 @@ int replay_tail(tr_scene *s)
         }
     } else {
         st = run_group(s, s->tail.params.data(), s->tail.fbs.empty() ? nullptr : s->tail.fbs.data(), s->tail.slot.data(), kept);
-        if (st == TR_OK) st = fence_setup_stream(s);
+        if (st == TR_OK) st = finish_groups(s);
     }
     if (st != TR_OK) return st;
     return use_slot(s, cur, cur_fb == s->slots[(size_t)cur].fb ? nullptr : cur_fb);  // the selection the caller had
@@ -1327,6 +1440,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->tile_mode = o.tile_mode;
     if (o.frames_per_launch > (uint32_t)GROUP_MAX) return tr::fail(TR_E_INVALID, "frames_per_launch must be 0 (automatic) or 1..16");
     s->frames_per_launch = o.frames_per_launch;
+    s->auto_group = (o.flags & TR_OPT_NO_AUTO_GROUP) == 0;
 
     if (o.stream) {
         s->stream = (hipStream_t)o.stream;
@@ -1624,7 +1738,32 @@ int tr_scene_render(tr_scene *s)
     s->last.shadow_cleared = s->shadow_cleared;
     s->last.valid = true;
     s->last_was_group = false;
-    return render_frame(s);
+    if (!frame_is_groupable(s)) {
+        // frames held back before it go first (it may render onto the last of them)
+        int st = flush_deferred(s, false);
+        if (st != TR_OK) return st;
+        return render_frame(s);
+    }
+    // a cleared frame on the library's own stream: recorded now, rendered with its neighbours ("Automatic frame
+    // groups").  Its constants are checked here, so that a camera the reference would panic on is this call's status.
+    s->host_status = TR_OK;
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    for (int i = 0; i < pd.n_passes; i++) {
+        DevUniforms du;
+        int st = pass_uniforms(s, pd.pass[i], du);
+        if (st != TR_OK) {
+            s->host_status = st;
+            return st;
+        }
+    }
+    tr_scene::DeferredFrame f;
+    memcpy(f.p.light, s->light, 12); memcpy(f.p.look_from, s->from, 12);
+    memcpy(f.p.look_at, s->at, 12); memcpy(f.p.up, s->up, 12);
+    f.fb = s->d_fb;
+    s->deferred.push_back(f);
+    s->z_fb_cleared = s->shadow_cleared = false;  // the frame has consumed the clear
+    if (s->deferred.size() >= (size_t)group_size(s)) return flush_deferred(s, true);
+    return TR_OK;
 }
 
 int tr_scene_render_frames(tr_scene *s, uint32_t n_frames, const tr_frame_params *frames, void *const *frame_buffers_device)
