@@ -339,9 +339,8 @@ def main():
     device_idle()
     t0 = time.perf_counter()
     run(args.steps)
-    device_idle()
-    barrier()
-    device_idle()
+    device_idle()   # this rank's frames are complete (flush + torch.cuda.synchronize()) ...
+    barrier()       # ... and so are everybody's: the clock stops at the slowest rank (max over ranks below)
     elapsed = time.perf_counter() - t0
     ok, status = clean_sync()
     if not ok:
@@ -373,7 +372,9 @@ def main():
         ok, orbit_status = clean_sync()
 
     # ---- the same steps through the reference's own per-frame protocol (four calls per frame) ---------
-    per_frame_elapsed, per_frame_steps = None, min(args.steps, 500)
+    # (a) as the library runs it by default: frames nobody reads in between are held back and fused;
+    # (b) with that switched off (TR_OPT_NO_AUTO_GROUP): one launch of each kernel per frame -- round 1's path
+    per_frame_elapsed, per_frame_steps, unfused_elapsed = None, min(args.steps, 500), None
     if extras and grouped:
         run(50, per_frame=True)
         device_idle()
@@ -382,6 +383,15 @@ def main():
         device_idle()
         per_frame_elapsed = time.perf_counter() - t1
         scene.sync()
+        scene.set_auto_group(False)   # (the same scene: a second one would share hardware queues with it)
+        run(50, per_frame=True)
+        device_idle()
+        t1 = time.perf_counter()
+        run(per_frame_steps, per_frame=True)
+        device_idle()
+        unfused_elapsed = time.perf_counter() - t1
+        scene.sync()
+        scene.set_auto_group(True)
 
     # ---- single-frame latency: clear -> render -> sync with nothing else in flight -----------------
     latency_us = None
@@ -571,8 +581,12 @@ def main():
             "per_frame_protocol": {"ms_per_step": round(per_frame_elapsed / per_frame_steps * 1e3, 5),
                                    "value": round(n_shaded * per_frame_steps / per_frame_elapsed / 1e6, 2),
                                    "steps": per_frame_steps,
-                                   "what": "the same frames through clear / set_light_direction / set_camera / render, "
-                                           "one launch of each kernel per frame"} if per_frame_elapsed else None,
+                                   "what": "the same frames through clear / set_light_direction / set_camera / render "
+                                           "(frames nobody reads in between are held back and fused by the library)",
+                                   "unfused_ms_per_step": round(unfused_elapsed / per_frame_steps * 1e3, 5),
+                                   "unfused_value": round(n_shaded * per_frame_steps / unfused_elapsed / 1e6, 2),
+                                   "unfused_what": "TR_OPT_NO_AUTO_GROUP: one launch of each kernel per frame"}
+            if per_frame_elapsed else None,
             "t_frame_us": t_frame,
             "latency_us": latency_us,
             "readback_inclusive_mpixels_per_s": round(n_shaded / readback / 1e6, 1) if readback else None,

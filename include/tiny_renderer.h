@@ -111,6 +111,7 @@ int tr_scene_set_camera(tr_scene *s, const float look_from[3], const float look_
  * tr_scene_flush and tr_scene_get_frame_buffer_async submit what is held back first, so a frame that is read
  * right after its render goes to the device alone, at once. */
 int tr_scene_render(tr_scene *s);
+int tr_scene_set_auto_group(tr_scene *s, int on); /* the same switch as TR_OPT_NO_AUTO_GROUP, at run time */
 
 /* Many frames per call -- the throughput path (nothing of the kind upstream, whose caller renders one frame per
  * window refresh, app.rs:170-213).  Frame i of the call is exactly what

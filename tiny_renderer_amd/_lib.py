@@ -76,6 +76,7 @@ SYMBOLS = {
     "tr_scene_set_light_direction": (C.c_int, [C.c_void_p, _FP]),
     "tr_scene_set_camera": (C.c_int, [C.c_void_p, _FP, _FP, _FP]),
     "tr_scene_render": (C.c_int, [C.c_void_p]),
+    "tr_scene_set_auto_group": (C.c_int, [C.c_void_p, C.c_int]),
     "tr_scene_render_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "tr_scene_frames_per_launch": (C.c_int, [C.c_void_p]),
     "tr_scene_frames_kept": (C.c_int, [C.c_void_p]),

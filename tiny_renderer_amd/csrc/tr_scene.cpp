@@ -1797,6 +1797,15 @@ int tr_scene_select_frame(tr_scene *s, uint32_t back)
     return use_slot(s, s->tail.slot[k], s->tail.fbs.empty() ? nullptr : (uint8_t *)s->tail.fbs[k]);
 }
 
+int tr_scene_set_auto_group(tr_scene *s, int on)
+{
+    if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = submit_pending(s);  // frames held back so far are rendered as they were issued
+    s->auto_group = on != 0;
+    return st;
+}
+
 int tr_scene_flush(tr_scene *s)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");

@@ -98,6 +98,10 @@ class Scene:
     def render(self):
         check(load_library().tr_scene_render(self._h))
 
+    def set_auto_group(self, on):
+        """Whether render() may hold cleared frames back to fuse them (default on; tr_scene_set_auto_group)."""
+        check(load_library().tr_scene_set_auto_group(self._h, 1 if on else 0))
+
     def render_frames(self, frames, frame_buffers_device=None):
         """tr_scene_render_frames: `frames` is an [n, 12] float32 array (or a list of (light, look_from,
         look_at, up) tuples): per frame light direction, look_from, look_at, up.  Frame i is what
