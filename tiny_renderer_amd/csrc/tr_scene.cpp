@@ -215,10 +215,12 @@ struct tr_scene {
         bool in_flight = false;
         uint32_t bin_cap = 0, frames = 0;  // what the set was allocated for
         uint32_t g = 0;                    // frames of the group it holds now
+        bool chain_on_main = false;        // its setup was queued on the main stream itself (nothing was in flight)
     } grp[GROUP_SETS];
     uint64_t group_seq = 0;       // groups whose setup has been queued
     uint64_t group_submitted = 0; // groups whose tile kernels have been queued (<= group_seq)
     bool groups_unfenced = false; // group tile kernels were queued since the setup stream was last ordered behind them
+    bool quiescent = false;       // the host has waited for the main stream and queued nothing since
     // Automatic frame groups: cleared frames rendered through the per-frame calls on the library's own stream
     // are held back until a group is full (or anything needs them) and then rendered by fused launches.
     struct DeferredFrame {
@@ -688,6 +690,7 @@ int sync_and_status(tr_scene *s)
         if (err & DE_BIN_OVERFLOW) return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins overflowed twice");
     }
     s->observed_seq = 0;
+    s->quiescent = true;  // (whatever a getter queues next -- a view kernel, a copy -- it also waits for)
     if (host_status != TR_OK) return host_status;
     if (err & (DE_W_ZERO | DE_TEX_OOB | DE_SHADOW_OOB | DE_SINGULAR)) {
         char buf[160];
@@ -789,27 +792,35 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.err = s->d_err;
     sa.overflow_seq = s->d_overflow_seq;
     sa.pass_seq = p_seq;
-    // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p
-    if (p_seq >= (uint64_t)LOOKAHEAD)
+    // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p.
+    // With NOTHING in flight (a frame rendered and read, rendered and read: the interactive loop) the chain has
+    // nothing to overlap with, and the hop between the streams -- event, wait packet, dispatch: 13-17 us -- is
+    // pure latency: then setup, work list and tiles go down the main stream in order.
+    // "Nothing in flight" is what the host KNOWS after it has waited for the stream (a loop that merely runs
+    // ahead of a fast GPU must keep its overlap: asking the stream instead cost small frames 7-16 %).
+    const bool chain_on_main = s->own_stream && s->quiescent && s->pending.empty() && s->group_submitted == s->group_seq;
+    s->quiescent = false;
+    hipStream_t chain = chain_on_main ? s->stream : s->setup_stream;
+    if (!chain_on_main && p_seq >= (uint64_t)LOOKAHEAD)
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
     const uint32_t n_tiles_pass = frame.ntx * frame.nty;
     if (!s->profiling) {
-        int rc = launch_setup(p.vs, sa, nullptr, 0, s->setup_stream, nullptr, nullptr);
+        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, s->setup_stream, nullptr,
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, chain, nullptr,
                           s->ev_setup[p_seq % RING]);
         if (rc) return launch_status(rc, "k_order");
     } else {
         // profiling: timing events on the dispatches themselves, then the pipeline's event separately
         EventPair ep = { take_event(s), take_event(s), K_SETUP, 1u };
-        int rc = launch_setup(p.vs, sa, nullptr, 0, s->setup_stream, ep.a, ep.b);
+        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
         if (s->mesh.n_tri) s->events.push_back(ep);
         EventPair eo = { take_event(s), take_event(s), K_ORDER, 1u };
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, s->setup_stream, eo.a, eo.b);
+        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, chain, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
         s->events.push_back(eo);
-        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], s->setup_stream));
+        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], chain));
     }
     TileArgs ta;
     ta.bins = bins;
@@ -848,6 +859,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
         return submit_pending_tiles(s);
     }
     // the library's own stream: see "Handing tile kernels to the main stream" above
+    if (chain_on_main) return submit_front(s, false);  // its setup is ahead of it in the same queue
     int status = TR_OK;
     if ((int)s->pending.size() > BATCH) {
         // steady state: the HOST waits for the oldest pending pass's setup (it completed long ago, or will
@@ -984,6 +996,10 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const uint32_t np = (uint32_t)pd.n_passes;
     tr_scene::GroupSet &gs = s->grp[s->group_seq % GROUP_SETS];
+    // nothing in flight (the first group after a sync): its setup goes down the main stream, ahead of its tile
+    // kernels, without the hop between the streams (see run_pass)
+    const bool chain_on_main = s->own_stream && s->quiescent && s->pending.empty() && s->group_submitted == s->group_seq;
+    s->quiescent = false;
     // the set's previous group must have left the GPU before its bins, counters and tables are written again;
     // this wait is also what keeps the host from running ahead of the GPU without bound
     if (gs.in_flight) {
@@ -1061,8 +1077,9 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
     if (st != TR_OK) return st;
 
     // tables to the device, then per pass: vertex stage + binning of all frames, their work lists
+    hipStream_t chain = chain_on_main ? s->stream : s->setup_stream;
     HIP_TRY(hipMemcpyAsync(gs.d_tables, gs.h_tables, (size_t)np * G * (sizeof(SetupArgs) + sizeof(TileArgs)),
-                           hipMemcpyHostToDevice, s->setup_stream));
+                           hipMemcpyHostToDevice, chain));
     for (uint32_t pi = 0; pi < np; pi++) {
         const PassDesc &pass = pd.pass[pi];
         const SetupArgs &sa0 = h_setup[(size_t)pi * G];
@@ -1072,16 +1089,17 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             ep.a = take_event(s); ep.b = take_event(s);
             eo.a = take_event(s); eo.b = take_event(s);
         }
-        int rc = launch_setup(pass.vs, sa0, d_setup + (size_t)pi * G, g, s->setup_stream, ep.a, ep.b);
+        int rc = launch_setup(pass.vs, sa0, d_setup + (size_t)pi * G, g, chain, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
-        rc = launch_order(nullptr, nullptr, n_tiles_pass, d_tile + (size_t)pi * G, g, s->setup_stream, eo.a, eo.b);
+        rc = launch_order(nullptr, nullptr, n_tiles_pass, d_tile + (size_t)pi * G, g, chain, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
         if (s->profiling) {
             if (s->mesh.n_tri) s->events.push_back(ep);
             s->events.push_back(eo);
         }
     }
-    HIP_TRY(hipEventRecord(gs.ev_setup, s->setup_stream));
+    HIP_TRY(hipEventRecord(gs.ev_setup, chain));
+    gs.chain_on_main = chain_on_main;
     gs.g = g;
     gs.in_flight = true;
     s->pass_seq += (uint64_t)g * np;
@@ -1132,7 +1150,7 @@ int submit_groups(tr_scene *s, bool all)
     int status = TR_OK;
     while (s->group_submitted < s->group_seq) {
         tr_scene::GroupSet &gs = s->grp[s->group_submitted % GROUP_SETS];
-        const bool ready = hipEventQuery(gs.ev_setup) == hipSuccess;
+        const bool ready = gs.chain_on_main || hipEventQuery(gs.ev_setup) == hipSuccess;  // (in order on the main stream: as good as done)
         if (!ready && !all) {
             // a main stream that has run dry (the first group of a call, typically) gets the group at once, behind
             // a wait: an idle GPU loses nothing to the packet, and a call of a few frames is mostly start-up
@@ -1877,6 +1895,7 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
     if (st != TR_OK) return st;
     // same stream as the tile kernels: after the frame, before the next one overwrites it
     HIP_TRY(hipMemcpyAsync(rgb, s->d_fb, (size_t)s->width * s->height * 3, hipMemcpyDeviceToHost, s->stream));
+    s->quiescent = false;
     // every pass issued so far is now in a consumer's hands: a bin overflow among them can no longer
     // be repaired by rendering again, and tr_scene_sync will say so (TR_E_BIN_OVERFLOW)
     s->observed_seq = s->pass_seq;
