@@ -174,7 +174,8 @@ def test_group_bin_overflow_renders_the_kept_frames_again(synthetic, pipe):
     gpu.close()
 
 
-def test_group_on_a_callers_stream_into_callers_buffers(small_synthetic):
+@pytest.mark.parametrize("pipe", ["phong", "shadow", "occlusion"])
+def test_group_on_a_callers_stream_into_callers_buffers(small_synthetic, pipe):
     """The multi-GPU pattern: a caller's stream, the caller's frame tensors as colour targets, the frames
     consumed on that stream without host synchronisation; a band scene writes its rows only."""
     import torch
@@ -186,7 +187,7 @@ def test_group_on_a_callers_stream_into_callers_buffers(small_synthetic):
     bufs = [torch.full((Hh * W * 3,), 77, dtype=torch.uint8, device="cuda") for _ in range(4)]
     kept = torch.zeros(n, Hh * W * 3, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    gpu = T.Scene(W, Hh, mesh, texs, "phong", stream=side.cuda_stream, frame_buffer_device=bufs[0].data_ptr(),
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, stream=side.cuda_stream, frame_buffer_device=bufs[0].data_ptr(),
                   band_rows=band, frames_per_launch=4)
     p = params(n)
     with torch.cuda.stream(side):
@@ -197,7 +198,7 @@ def test_group_on_a_callers_stream_into_callers_buffers(small_synthetic):
                 kept[i0 + j].copy_(bufs[j], non_blocking=True)
     assert gpu.sync() == 0
     torch.cuda.synchronize()
-    expect = oracle_frames(W, Hh, mesh, texs, "phong", p, band=band)
+    expect = oracle_frames(W, Hh, mesh, texs, pipe, p, band=band)
     for i in range(n):
         got = kept[i].cpu().numpy().reshape(Hh, W, 3)
         assert np.array_equal(got[band[0]:band[1]], expect[i][0][band[0]:band[1]]), "frame %d" % i
