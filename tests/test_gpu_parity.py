@@ -690,6 +690,20 @@ def test_cli_sharded_single_rank(synthetic, tmp_path):
     assert np.array_equal(got, _oracle_frame(512, 384, mesh, texs, "shadow", angle, 0.5))
 
 
+def test_sharded_scene_render_frames(built):
+    """ShardedScene.render_frames (a rank's band of a GROUP of frames per kernel launch, the bands exchanged frame by
+    frame on the second stream) in a one-rank RCCL group, in its own process: tests/sharded_groups_worker.py."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "tests", "sharded_groups_worker.py")], env=env, cwd=H.REPO,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout + r.stderr)[-3000:]
+
+
 def test_peer_exchange_two_processes_one_gpu(diablo):
     """The library's own frame exchange (tr_exchange_*: HIP IPC mapped frame slots, concurrent DMA-engine
     band copies, generation flags) with TWO rank processes sharing this box's one GPU: bench.py's N = 2

@@ -126,8 +126,9 @@ def _run(args, T, scene, sharded, rank, say):
     angles = [np.float32(args.camera_angle + (2.0 * np.pi * f / args.frames if args.frames > 1 else 0.0))
               for f in range(args.frames)]
     la = np.float32(args.light_angle)
-    if args.frames > 1 and not sharded:
-        # many frames, one GPU: the library's throughput path (the same frames, several per kernel launch)
+    if args.frames > 1:
+        # many frames: the library's throughput path (the same frames, several per kernel launch; with --gpus every
+        # rank renders its band of a group, and the bands are exchanged frame by frame)
         p = np.zeros((args.frames, 12), np.float32)
         p[:, 0:3] = [float(np.sin(la)), 0.0, float(np.cos(la))]
         for f, ca in enumerate(angles):

@@ -83,6 +83,8 @@ class ShardedScene:
         self._cleared = True    # Scene::new leaves cleared (zero-filled) targets
         self._used = [False, False]
         self._last_was_cleared = True
+        self._last_tensor = None   # where the newest frame is when it came from render_frames (else _fbs[_slot])
+        self._last_group = None    # (frames, set) of the newest group: rendered again if its bins overflowed
 
     # --- the reference's methods -------------------------------------------------------------
     def clear(self):
@@ -117,6 +119,53 @@ class ShardedScene:
         self._used[b] = True
         self._last_was_cleared = self._cleared
         self._cleared = False
+        self._last_tensor = None
+        self._last_group = None
+
+    def render_frames(self, frames):
+        """Many frames per call (Scene.render_frames on every rank): each rank renders its band of a group of
+        frames by one launch of each kernel into a set of frame tensors of the group's size, and the bands
+        of the group are exchanged frame by frame on the second stream while the next group renders into
+        the other set.  Frame i is what clear(); set_light_direction; set_camera; render() gives; afterwards
+        the last frame is the one get_frame_buffer() returns.  Collective: all ranks pass the same frames."""
+        import numpy as np
+        torch, dist = self._torch, self._dist
+        frames = np.ascontiguousarray(frames, np.float32).reshape(-1, 12)
+        if len(frames) == 0:
+            return
+        G = self._scene.frames_per_launch
+        if not hasattr(self, "_gsets"):
+            n_all = self.width * self.height * 3
+            dev = self._fbs[0].device
+            self._gsets = [[torch.zeros(n_all, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(2)]
+            self._grendered = [torch.cuda.Event() for _ in range(2)]
+            self._ggathered = [torch.cuda.Event() for _ in range(2)]
+            self._gused = [False, False]
+            self._gset = 1
+        n = (self.band[1] - self.band[0]) * self.width * 3
+        for i0 in range(0, len(frames), G):
+            g = min(G, len(frames) - i0)
+            self._gset ^= 1
+            b = self._gset
+            with torch.cuda.stream(self._render):
+                if self._gused[b]:
+                    self._render.wait_event(self._ggathered[b])   # the set's previous exchange has finished
+                self._scene.render_frames(frames[i0:i0 + g], [t.data_ptr() for t in self._gsets[b][:g]])
+                self._grendered[b].record(self._render)
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(self._grendered[b])
+                for j in range(g):
+                    t = self._gsets[b][j]
+                    dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n])
+                self._ggathered[b].record(self._comm)
+            self._gused[b] = True
+            self._last_group = (frames[i0:i0 + g].copy(), b)
+        self._last_tensor = self._gsets[self._gset][g - 1]
+        q = frames[-1]
+        self._scene.set_light_direction(q[0:3])
+        self._scene.set_camera(q[3:6], q[6:9], q[9:12])
+        self._cleared = False
+        self._last_was_cleared = True
 
     def sync(self):
         """Waits for the frames issued so far on every rank (collective: all ranks call it together).
@@ -138,6 +187,11 @@ class ShardedScene:
                 return status
             if not self._last_was_cleared:
                 raise TinyRendererError(TR_E_BIN_OVERFLOW, "bins overflowed during an accumulating render: clear and render again")
+            if self._last_group is not None:
+                again, b = self._last_group
+                self._gset = b ^ 1       # ... into the same set of frame tensors
+                self.render_frames(again)
+                continue
             self._scene.clear()          # same light and camera: the scene still holds them
             self._cleared = True
             self._slot ^= 1              # ... and the same frame tensor
@@ -149,7 +203,8 @@ class ShardedScene:
         status = self.sync()
         if status != 0:
             raise RuntimeError("device status %d" % status)
-        return self._fbs[self._slot].cpu().numpy().reshape(self.height, self.width, 3)
+        t = self._last_tensor if self._last_tensor is not None else self._fbs[self._slot]
+        return t.cpu().numpy().reshape(self.height, self.width, 3)
 
     def close(self):
         self._torch.cuda.synchronize()
