@@ -740,11 +740,16 @@ int pass_uniforms(tr_scene *s, const PassDesc &p, DevUniforms &du)
 // A fused launch (tr_scene_render_frames) fills the GPU with the tiles of ALL its frames, so its waves per
 // tile go by that total; whether its waves share a tile's bin still goes by the size of ONE frame, which is
 // what decides how unevenly the polygons fall on a tile's columns (800^2 african_head, 16 frames per launch,
-// k_tile per frame: 4 waves columns 4.6 us, 4 waves shared 3.3, 8 shared 3.6, 16 shared 4.4).
+// k_tile per frame: 4 waves columns 4.6 us, 4 waves shared 3.3, 8 shared 3.6, 16 shared 4.4) ...
 void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, uint32_t tiles_per_frame, int &tile_waves, int &shared)
 {
     tile_waves = s->tile_waves ? (int)s->tile_waves : tiles_in_launch <= 1024u ? 16 : tiles_in_launch <= 4608u ? 8 : 4;
-    shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto(tiles_per_frame <= 2048u ? 1 : 0);
+    // ... or by how many polygons a tile gets: many small ones are visited once per tile instead of once per
+    // column they touch.  k_tile per frame, columns -> shared, polygons per tile of the frame: 8192^2 x64 grid
+    // specular (9.8) 371 -> 350 us, the same with phong 259 -> 230, 4096^2 x16 (9.8) 66.9 -> 60.0, x9 (5.5)
+    // 50.4 -> 47.6, x4 (2.5) 38.9 -> 38.5, one model (0.6) 33.5 -> 35.4
+    const bool dense = (uint64_t)s->mesh.n_tri >= 3ull * (tiles_per_frame ? tiles_per_frame : 1u);
+    shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto((tiles_per_frame <= 2048u || dense) ? 1 : 0);
 }
 
 int run_pass(tr_scene *s, const PassDesc &p)
