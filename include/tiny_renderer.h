@@ -85,8 +85,8 @@ typedef struct tr_options {
                                   sees every polygon of the bin, 2 = each owns a share of the bin and sees the
                                   whole tile (depth resolve through LDS atomics), 0 = automatic.
                                   Speed only: results do not depend on it. */
-    uint32_t frames_per_launch; /* tr_scene_render_frames: frames rendered by one launch of each kernel (1..16), 0 =
-                                  automatic (by tile count: 4 at 4096x4096, 16 for small frames).  Speed only. */
+    uint32_t frames_per_launch; /* tr_scene_render_frames: frames rendered by one launch of each kernel (1..32), 0 =
+                                  automatic (by tile count: 4 at 4096x4096, 32 for small frames).  Speed only. */
 } tr_options;
 
 typedef struct tr_scene tr_scene;

@@ -16,7 +16,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100):
     waves = [4, 8, 16, 0][seed % 4]
     pipe = ["phong", "normal_map", "default", "darboux", "specular", "shadow", "occlusion"][(seed // 2) % 7]
     mesh, texs = (far_soup(19000 + seed, int(rng.integers(20, 300))) if seed % 3 else soup(500 + seed, int(rng.integers(20, 400)), int(rng.choice([2, 3, 5, 9]))))
-    fpl = int(rng.choice([2, 3, 4, 8, 16, 0]))
+    fpl = int(rng.choice([2, 3, 4, 8, 16, 32, 0]))
     n = int(rng.integers(2, 10))
     views = [(float(rng.choice([0.0, 0.3, -1.2, 3.14159])), float(rng.uniform(-1, 1))) for _ in range(n)]
     expect = []

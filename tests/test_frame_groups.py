@@ -81,8 +81,8 @@ def test_group_frames_match_the_oracle(synthetic, pipe):
     gpu.close()
 
 
-@pytest.mark.parametrize("fpl", [1, 2, 3, 8, 16, 0])
-@pytest.mark.parametrize("n", [1, 5, 16, 19])
+@pytest.mark.parametrize("fpl", [1, 2, 3, 8, 16, 32, 0])
+@pytest.mark.parametrize("n", [1, 5, 16, 19, 70])
 def test_group_sizes_and_counts(small_synthetic, fpl, n):
     import tiny_renderer_amd as T
     mesh, texs = small_synthetic

@@ -120,7 +120,7 @@ constexpr int RING = 16;  // events: pass p's are waited for until pass p + LOOK
 // frame into a frame slot of its own (z, colour, fast-clear flags, shadow buffer).  Same replicated frame,
 // k_tile per frame (us, group of 1 / 2 / 4 / 8): 4096^2 phong 33.9 / 29.0 / 27.0 / 27.0, darboux 65.9 / 59.5 /
 // 58.9 / 56.3, 2048^2 phong 21.3 / 14.2 / 12.6 / 12.0, 800^2 26.3 / 12.8 / 7.4 / 4.5, 512^2 22.5 / 12.2 / 6.6 / 3.6.
-constexpr int GROUP_MAX = 16;   // frames per fused launch, at most
+constexpr int GROUP_MAX = 32;   // frames per fused launch, at most
 constexpr int GROUP_SETS = 4;   // groups in flight: group g's setup reuses the bins of group g - GROUP_SETS
 
 struct tr_scene {
@@ -1461,7 +1461,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->tile_waves = o.tile_waves;
     if (o.tile_mode > 2) return tr::fail(TR_E_INVALID, "tile_mode must be 0 (automatic), 1 (columns) or 2 (shared bin)");
     s->tile_mode = o.tile_mode;
-    if (o.frames_per_launch > (uint32_t)GROUP_MAX) return tr::fail(TR_E_INVALID, "frames_per_launch must be 0 (automatic) or 1..16");
+    if (o.frames_per_launch > (uint32_t)GROUP_MAX) return tr::fail(TR_E_INVALID, "frames_per_launch must be 0 (automatic) or 1..32");
     s->frames_per_launch = o.frames_per_launch;
     s->auto_group = (o.flags & TR_OPT_NO_AUTO_GROUP) == 0;
 
