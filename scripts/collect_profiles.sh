@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --stats -d "$out/trace" -o out --output-format csv -- p
     > "$out/bench_under_rocprof.log" 2> "$out/trace.err" || exit 1
 tail -n 1 "$out/bench_under_rocprof.log"
 
-# (frames: multiples of the workload's frames per launch -- 4, 32, 8, 4, 4, 4 -- so that every launch is a full group)
+# (frames: multiples of the workload's frames per launch -- 4, 32, 16, 4, 4, 4 -- so that every launch is a full group)
 # tag            size pipeline frames model        grid
 workloads=(
  "headline       4096 phong    32     diablo       1"
