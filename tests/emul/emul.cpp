@@ -78,7 +78,8 @@ struct VaryPair {
     f2 operator()(int k) const { return mk2(a[k], b[k]); }
 };
 
-uint64_t g_pair_fast = 0, g_pair_plain = 0;  // how often the two-pixel closures' guard let the fast form stand
+uint64_t g_pair_fast = 0, g_pair_plain = 0;
+uint64_t g_mask_violations = 0, g_mask_cells_live = 0, g_mask_cells_box = 0;  // pair_masks: covered pixels in dead cells; culling rate  // how often the two-pixel closures' guard let the fast form stand
 
 // The kernel's use of the two-pixel closures: both pixels together; if either survivor left the guarded
 // range (`plain` stays true) the caller runs the plain closure for both.
@@ -221,14 +222,34 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                 e2.a0 = splat2(la0); e2.a1 = splat2(la1); e2.b0 = splat2(lb0); e2.b1 = splat2(lb1);
                 e2.cz = splat2(lcz);
                 e2.y = splat2(lry);
+                // what k_setup stores with this (polygon, tile) pair: the cells / block columns that can hold a
+                // fragment.  Pixels outside them are skipped, as the tile kernel skips them; a covered pixel
+                // found there is a violation of the masks' conservativeness (counted, and the frame is wrong).
+                uint32_t mlo = 0, mhi = 0;
+                pair_masks(r, tile_x0, tile_y0, mlo, mhi);
+                const PairBox pb = pair_box(r.bx0, r.bx1, r.by0, r.by1, tile_x0, tile_y0);
+                const bool small_pair = pb.nch <= SCAN_MAX_CHUNKS;
+                const uint32_t cols = pair_block_columns(mlo, mhi, pb, tile_x0);
+                if (small_pair) {
+                    g_mask_cells_live += (uint64_t)(__builtin_popcount(mlo) + __builtin_popcount(mhi));
+                    g_mask_cells_box += (uint64_t)(pb.nch * (pb.ay1 - pb.ay0 + 1));
+                }
                 for (int32_t py = by0; py <= by1; py++)
                     for (int32_t px = bx0; px <= bx1; px += 2) {
                         const bool second = px + 1 <= bx1;  // the pair's second pixel (px + 1, py)
                         f2 cx, cy;
                         edge_cross2(e2, mk2((float)isub(r.x0, px), (float)isub(r.x0, px + 1)), splat2((float)isub(r.y0, py)), cx, cy);
                         const f2 rest = e2.cz - (cx + cy);
-                        const bool hit[2] = { covers_oriented(cx.x, cy.x, lcz), second && covers_oriented(cx.y, cy.y, lcz) };
+                        bool hit[2] = { covers_oriented(cx.x, cy.x, lcz), second && covers_oriented(cx.y, cy.y, lcz) };
                         (void)rest;
+                        for (int h = 0; h < 2; h++) {
+                            const int32_t x = px + h;
+                            const uint32_t cell = (uint32_t)((py - pb.ay0) * 4 + ((x - pb.xs) >> 3));
+                            const bool in_cell = !small_pair || (((cell < 32u ? mlo >> cell : mhi >> (cell - 32u)) & 1u) != 0u);
+                            const bool in_col = ((cols >> ((x - tile_x0) >> 3)) & 1u) != 0u;
+                            if (hit[h] && !(in_cell && in_col)) g_mask_violations++;
+                            hit[h] = hit[h] && in_cell && in_col;
+                        }
                         if (!hit[0] && !hit[1]) continue;
                         const Bary2 bar = barycentric2_for_compare(cx, cy, e2);
                         const f2 z2 = dot3_2(bar.x, bar.y, bar.z, splat2(r.z0), splat2(r.z1), splat2(r.z2));
@@ -397,6 +418,15 @@ extern "C" uint32_t tr_emul_decode_normal_mismatches(uint32_t first, uint32_t co
                memcmp(&p.x.y, &b.x, 4) != 0 || memcmp(&p.y.y, &b.y, 4) != 0 || memcmp(&p.z.y, &b.z, 4) != 0;
     }
     return bad;
+}
+
+// pair_masks statistics since the library was loaded: {covered pixels found outside the masks (must be 0),
+// live cells of small pairs, cells of their boxes}
+extern "C" void tr_emul_mask_counts(uint64_t out[3])
+{
+    out[0] = g_mask_violations;
+    out[1] = g_mask_cells_live;
+    out[2] = g_mask_cells_box;
 }
 
 extern "C" void tr_emul_pair_counts(uint64_t out[2])

@@ -27,10 +27,19 @@ def lib():
                                                       C.c_void_p, C.c_void_p, C.c_uint32]
         L.tr_emul_pair_counts.restype = None
         L.tr_emul_pair_counts.argtypes = [C.POINTER(C.c_uint64)]
+        L.tr_emul_mask_counts.restype = None
+        L.tr_emul_mask_counts.argtypes = [C.POINTER(C.c_uint64)]
         L.tr_emul_powf.restype = C.c_int
         L.tr_emul_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _lib = L
     return _lib
+
+
+def mask_counts():
+    """{covered pixels found outside pair_masks' cells (must stay 0), live cells, box cells} so far."""
+    out = (C.c_uint64 * 3)()
+    lib().tr_emul_mask_counts(out)
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def render(W, Hh, mesh, texs, pipe, light, cam, fresh=1, bufs=None, band=(0, 0)):

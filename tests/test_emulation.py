@@ -87,3 +87,39 @@ def test_bands_reassemble(small_synthetic):
         _, _, _, part, _ = E.render(W, Hh, mesh, texs, "phong", H.light(0.3), H.camera(0.3), band=(r0, r1))
         out[r0:r1] = part[r0:r1]
     assert np.array_equal(out, fb)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pair_masks_never_lose_a_fragment(seed):
+    """k_setup stores with every (polygon, tile) pair which cells / block columns of the box can hold a
+    fragment (pair_masks, tr_shaders.h) and the tile kernel looks nowhere else.  The emulation skips the
+    same pixels: far-away vertices, slivers and nearly collinear triples (edge functions that round in
+    f32) are where a margin that is too small would lose fragments -- the frame must stay the oracle's
+    and no covered pixel may lie outside the masks."""
+    from tests.test_random_meshes import far_soup
+    W, Hh = [(8192, 48), (4096, 130), (1000, 1000)][seed % 3]
+    mesh, texs = far_soup(7000 + seed, 160)
+    before = E.mask_counts()
+    s = O.Scene(W, Hh, mesh, texs, "phong")
+    s.clear()
+    s.set_light_direction(H.light(0.4))
+    s.set_camera(*H.camera(0.0))
+    if s.render() != 0:
+        pytest.skip("the reference would panic on this soup")
+    err, z, sh, fb, win = E.render(W, Hh, mesh, texs, "phong", H.light(0.4), H.camera(0.0))
+    after = E.mask_counts()
+    assert after[0] == before[0], "covered pixels outside the pair masks"
+    assert np.array_equal(win, s.winner_u32())
+    assert np.array_equal(z.view(np.uint32), s.z_f32().view(np.uint32))
+    assert np.array_equal(fb, s.get_frame_buffer())
+
+
+def test_pair_masks_cull_cells(diablo):
+    """... and they do cull: on diablo at 800x800 fewer than two thirds of the small pairs' box cells stay."""
+    mesh, texs = diablo
+    before = E.mask_counts()
+    assert_same(*run_both(800, 800, mesh, texs, "phong", 0.7, -1.1), "phong")
+    after = E.mask_counts()
+    assert after[0] == before[0]
+    live, box = after[1] - before[1], after[2] - before[2]
+    assert box > 10000 and live < 0.67 * box, (live, box)

@@ -47,25 +47,25 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 // -----------------------------------------------------------------------------------------
 // k_setup
 // -----------------------------------------------------------------------------------------
-constexpr uint32_t SETUP_POLYS = 16;  // polygons per 64-lane workgroup of k_setup
+constexpr uint32_t SETUP_POLYS = 64;  // polygons per 64-lane workgroup of k_setup, at most (launch_setup chooses)
 
 template <int VS>
-__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
+__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, uint32_t polys)
 {
     constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     __shared__ uint4 s_rec[SETUP_POLYS * P];
+    __shared__ RasterRec s_rast[SETUP_POLYS];
     __shared__ int32_t s_excl[64], s_tx0[64], s_ty0[64], s_ntx[64];
 
-    // A wave takes only SETUP_POLYS polygons (the other lanes idle through the short vertex
-    // stage) but all 64 lanes share the binning below: the polygons of one wave can span hundreds
-    // of tiles, and the wave with the most (polygon, tile) pairs is the kernel's critical path.
-
+    // Lane = polygon for the vertex stage (the first `polys` lanes: a small mesh is spread over more waves
+    // than it has sixty-fourths, because the wave with the most (polygon, tile) pairs is the kernel's
+    // critical path and a lone frame waits for it); all 64 lanes then share the binning below.
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = block * SETUP_POLYS + lane;
+    const uint32_t t = block * polys + lane;
 
     int32_t tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
     uint32_t err = 0;
-    if (lane < SETUP_POLYS && t < a.mesh.n_tri) {
+    if (lane < polys && t < a.mesh.n_tri) {
         RasterRec r;
         float v[VARY_STRIDE];
 #pragma unroll
@@ -77,7 +77,9 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
             mark_rejected(r);
         if (r.bx0 <= r.bx1) {
             uint4 *o = s_rec + lane * P;
-            o[0] = make_uint4((uint32_t)r.bx0, (uint32_t)r.bx1, (uint32_t)r.by0, (uint32_t)r.by1);
+            // piece 0: the clamped box (coordinates below 2^15) and, per tile, the pair's coverage masks
+            // (pair_masks, tr_shaders.h: filled in when the record is appended to a bin)
+            o[0] = make_uint4((uint32_t)r.bx0 | ((uint32_t)r.bx1 << 16), (uint32_t)r.by0 | ((uint32_t)r.by1 << 16), 0u, 0u);
             // vertex 0 and the two edge vectors from it, the latter already as the f32 values every
             // pixel's to_barycentric_coord starts from (scene.rs:178-181: integer difference, then
             // the conversion) -- the tile kernel's shading phase used to redo these 8 subtractions
@@ -93,6 +95,7 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
             // spare last word (varying 9 / 21 is unused): RN(1 / cross.z), the one IEEE division
             // per polygon; k_tile derives every per-pixel quotient from it (tr_math.h div_by)
             o[P - 1].w = __float_as_uint(record_recip(r));
+            s_rast[lane] = r;
             tx0 = r.bx0 / TILE_W;
             ty0 = r.by0 / TILE_H;
             ntx = r.bx1 / TILE_W - tx0 + 1;
@@ -120,13 +123,14 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
 
     constexpr int PAIRS = 8;  // pairs per lane per trip: their atomics are in flight together
     for (int32_t p0 = (int32_t)lane; p0 < total; p0 += 64 * PAIRS) {
-        int32_t own[PAIRS], tile[PAIRS];
+        int32_t own[PAIRS], tile[PAIRS], ptx[PAIRS], pty[PAIRS];
         uint32_t slot[PAIRS];
 #pragma unroll
         for (int k = 0; k < PAIRS; k++) {
             const int32_t p = p0 + 64 * k;
             own[k] = -1;
             tile[k] = 0;
+            ptx[k] = pty[k] = 0;
             if (p < total) {
                 // owner = last lane whose exclusive offset is <= p (lanes without pairs share
                 // their successor's offset, so "last" skips them)
@@ -141,7 +145,9 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
                 }
                 const int32_t q = p - s_excl[lo], w = s_ntx[lo];
                 own[k] = lo;
-                tile[k] = tile_index(a.frame, s_tx0[lo] + q % w, s_ty0[lo] + q / w);
+                ptx[k] = s_tx0[lo] + q % w;
+                pty[k] = s_ty0[lo] + q / w;
+                tile[k] = tile_index(a.frame, ptx[k], pty[k]);
             }
         }
 #pragma unroll
@@ -154,8 +160,13 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
             if (slot[k] < a.bin_cap) {
                 uint4 *dst = reinterpret_cast<uint4 *>(a.bins) + ((size_t)tile[k] * a.bin_cap + slot[k]) * P;
                 const uint4 *src = s_rec + own[k] * P;
+                // which cells (small pair) or block columns (large pair) of the box inside THIS tile can hold
+                // a fragment: the tile kernel evaluates no edge function to find its work
+                uint4 head = src[0];
+                pair_masks(s_rast[own[k]], ptx[k] * TILE_W, pty[k] * TILE_H, head.z, head.w);
+                dst[0] = head;
 #pragma unroll
-                for (int i = 0; i < P; i++) dst[i] = src[i];
+                for (int i = 1; i < P; i++) dst[i] = src[i];
             } else {
                 atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
                 atomicMax(a.bin_need, slot[k] + 1u);
@@ -166,9 +177,9 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
 }
 
 template <int VS>
-__global__ __launch_bounds__(64) void k_setup(SetupArgs a)
+__global__ __launch_bounds__(64) void k_setup(SetupArgs a, uint32_t polys)
 {
-    setup_body<VS>(a, blockIdx.x);
+    setup_body<VS>(a, blockIdx.x, polys);
 }
 
 // Read-only argument tables of the fused launches: viewed in the constant address space, so that the loads
@@ -180,9 +191,9 @@ using constant_ptr = const __attribute__((address_space(4))) T *;
 // The same for a group of frames in one launch (tr_scene_render_frames): blockIdx.y = frame, whose
 // arguments are entry y of a table in device memory.
 template <int VS>
-__global__ __launch_bounds__(64) void k_setup_group(const SetupArgs *__restrict__ table)
+__global__ __launch_bounds__(64) void k_setup_group(const SetupArgs *__restrict__ table, uint32_t polys)
 {
-    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x);
+    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x, polys);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -298,6 +309,14 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t tx, uint32_t qy)
     return (tx / (uint32_t)QUAD) * (uint32_t)QPIX + (((qy >> 3) * NBX + (qx >> 3)) << 6) + ((qy & 7u) << 3) + (qx & 7u);
 }
 
+// Key layout of the SHARED resolve: row-major, the 8-pixel groups of a row rotated by the row number.
+// Pixels x and x + 1 (x even) are neighbours -- a scan-line item reads both keys with one 16-byte
+// access -- and a wave that sweeps a block column (lane = 8 x 8 pixels) still touches every bank once.
+__device__ __forceinline__ uint32_t shared_key_slot(uint32_t tx, uint32_t qy)
+{
+    return qy * (uint32_t)TILE_W + (tx ^ ((qy & 7u) << 3));
+}
+
 // Streams the cleared value of a tile (scene.rs:128-137 folded into the render): z / shadow =
 // f32::MIN, rgb = 0.  Whole-tile rows are whole cache lines; 16 B per lane when width % 16 == 0.
 template <bool DEPTH, int TILE_THREADS>
@@ -402,6 +421,12 @@ constexpr int tile_waves_per_eu(int fs, int tile_waves, bool group = false)
 // Field limits: polygon ids below 2^20, bin slots below 4093 (launch_tile falls back to the column
 // mode beyond them).
 constexpr uint32_t SHARED_MAX_POLYGONS = 1u << 20, SHARED_MAX_SLOTS = 4093u;
+// Shared resolve: small polygons (pair_masks, tr_shaders.h) are resolved as scan-line items (k_tile);
+// 0 = every polygon is visited by a whole wave (round 2's only form).
+#ifndef TR_SCAN_ITEMS
+#define TR_SCAN_ITEMS 1
+#endif
+constexpr bool SCAN_ITEMS = TR_SCAN_ITEMS != 0;
 __device__ __forceinline__ uint32_t depth_order_bits(float z)
 {
     uint32_t b = __float_as_uint(z);
@@ -450,6 +475,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     // order bits, .x = tie-break word whose low 12 bits are the bin slot + 1).
     __shared__ uint2 s_key[TILE_W * TILE_H];
     __shared__ uint4 s_rec[NMAX * P];
+    // shared resolve: running sums of the scan-line items per thread, and per wave
+    __shared__ uint32_t s_incl[SHARED ? TILE_THREADS : 1];
+    __shared__ uint32_t s_wtot[SHARED ? TILE_WAVES : 1];
 
     // One workgroup per tile, in the order k_order laid out: tiles with polygons first -- the long,
     // VALU-bound ones, heaviest first (longest-processing-time-first packing, and the machine is
@@ -520,9 +548,11 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         constexpr int QPIX = QUAD * TILE_H;
         const int32_t qx0 = SH ? tile_x0 : tile_x0 + (int32_t)wave * QUAD;
         uint2 *wkey = SH ? s_key : s_key + wave * QPIX;
+        // this lane's key in block column 0 (block row 0; block row 1 follows SH ? 8 rows : NBX blocks later)
+        const uint32_t key_lane = SH ? shared_key_slot((uint32_t)lx, (uint32_t)ly) : lane;
         // ---- initial keys -------------------------------------------------------------------
         if (SH) {
-            // the waves initialise the tile's blocks between them (block b of the block-major key array)
+            // the waves initialise the tile's blocks between them
             for (int b = (int)wave; b < NBX * NBY; b += TILE_WAVES) {
                 uint32_t zb = TR_F32_MIN_BITS;
                 if (!zfresh) {
@@ -530,7 +560,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
                         zb = __float_as_uint(depth[(size_t)py * W + px]);
                 }
-                wkey[(b << 6) + lane] = make_uint2(PREV_TAG, depth_order_bits(__uint_as_float(zb)));
+                wkey[shared_key_slot((uint32_t)((b % NBX) * 8 + lx), (uint32_t)((b / NBX) * 8 + ly))] =
+                    make_uint2(PREV_TAG, depth_order_bits(__uint_as_float(zb)));
             }
         } else {
     #pragma unroll
@@ -562,7 +593,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             // wave jj mod TILE_WAVES, a round covers 64 * TILE_WAVES records
             for (uint32_t j0 = 0; j0 < m; j0 += SH ? 64u * (uint32_t)TILE_WAVES : 64u) {
                 const uint32_t jj = SH ? j0 + lane * (uint32_t)TILE_WAVES + wave : j0 + lane;
-                uint4 r0 = make_uint4(1u, 0u, 1u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
+                uint4 r0 = make_uint4(1u, 0u, 0u, 0u), r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;  // (no record: an empty box)
                 uint32_t ry = 0u;
                 if (jj < m) {
                     r0 = s_rec[jj * P + 0];
@@ -571,6 +602,23 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     r3 = s_rec[jj * P + 3];
                     ry = s_rec[jj * P + (P - 1)].w;
                 }
+                // piece 0: the polygon's clamped box and what k_setup found out about it inside THIS tile
+                // (pair_masks, tr_shaders.h): the cells of a small pair, the block columns of a large one
+                const int32_t rbx0 = (int32_t)(r0.x & 0xFFFFu), rbx1 = (int32_t)(r0.x >> 16);
+                const int32_t rby0 = (int32_t)(r0.y & 0xFFFFu), rby1 = (int32_t)(r0.y >> 16);
+                const PairBox pb = pair_box(rbx0, rbx1, rby0, rby1, tile_x0, qy0);
+                const bool some = rbx0 <= rbx1;
+                // Shared form: a SMALL polygon -- its box inside the tile at most SCAN_MAX_CHUNKS 8-pixel chunks
+                // wide -- is not visited by a whole wave (135 instructions of broadcast and prologue for a
+                // polygon of a hundred pixels, then 128 pixel slots per step of which a third lie in its
+                // box): the live cells of its box (one row x one chunk each) become ITEMS, and the items of
+                // all the tile's small polygons are dealt to the lanes of all its waves (below).
+                const bool small = SH && SCAN_ITEMS && some && pb.nch <= SCAN_MAX_CHUNKS;
+                const uint32_t items = small ? (uint32_t)(__popc(r0.z) + __popc(r0.w)) : 0u;
+                // block columns of this wave's region (bit i = column pair i: block rows 0 / 1) with a live
+                // block: what a visit iterates over
+                uint32_t lmask = (some && !small) ? pair_block_columns(r0.z, r0.w, pb, tile_x0) : 0u;
+                if (!SH) lmask = (lmask >> (NBX * wave)) & ((1u << NBX) - 1u);
                 // The polygon's part of to_barycentric_coord (scene.rs:178-187), for the 64 records
                 // of this round at once (lane l = record l).  Orientation is normalised so that
                 // cross.z > 0: negating a0, a1, b0, b1 flips the sign of cross.x and cross.y exactly,
@@ -585,64 +633,13 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     lcz = -lcz;
                     lry = -lry;
                 }
-                // Which 8x8 blocks of this wave's region (NBX columns x 2 rows; bit i + NBX j) can hold a
-                // fragment of polygon l?  Its clamped box must meet the block, and the block must not lie
-                // wholly outside one of the three edges: cross.x, cross.y and cross.z - (cross.x + cross.y)
-                // are linear in the pixel, so their largest value over a block is the value at its origin
-                // plus 7 (|d/dx|+ + |d/dy|+).  A block is dropped only when that maximum misses zero by more
-                // than a bound on the f32 rounding of both this estimate and the per-pixel evaluation, so no
-                // pixel the exact test accepts is lost (the estimate may use fused operations: it decides
-                // nothing else).  Polygons without a live block are never visited, dead column pairs of
-                // the others are skipped: 134 K -> about 70 K block pairs at diablo 4096^2.
-                uint32_t lmask = 0u;
-                {
-                    const float ox = (float)isub((int32_t)r1.x, qx0), oy = (float)isub((int32_t)r1.y, qy0);
-                    const float e0x = lb1, e0y = -la1, e1x = -lb0, e1y = la0;
-                    const float e2x = lb0 - lb1, e2y = la1 - la0;
-                    const float e0 = la1 * oy - ox * lb1, e1 = ox * lb0 - la0 * oy;
-                    const float e2 = lcz - (e0 + e1);
-                    const float margin = 4.76837158e-7f /* 2^-21 */ *
-                                         (((fabsf(la1) + fabsf(la0)) * (fabsf(oy) + 16.0f) +
-                                           (fabsf(lb1) + fabsf(lb0)) * (fabsf(ox) + 32.0f)) + lcz);
-                    const float m0 = e0 + (7.0f * (fmaxf(e0x, 0.0f) + fmaxf(e0y, 0.0f)) + margin);
-                    const float m1 = e1 + (7.0f * (fmaxf(e1x, 0.0f) + fmaxf(e1y, 0.0f)) + margin);
-                    const float m2 = e2 + (7.0f * (fmaxf(e2x, 0.0f) + fmaxf(e2y, 0.0f)) + 2.0f * margin);
-                    // edge tests of all blocks, straight-line (no short-circuit: the compiler turned `&&` chains
-                    // into an exec-mask branch per block, a dozen scalar instructions each)
-                    uint32_t edge = 0u;
-    #pragma unroll
-                    for (int j = 0; j < NBY; j++) {
-                        const float n0 = __builtin_fmaf(8.0f * j, e0y, m0), n1 = __builtin_fmaf(8.0f * j, e1y, m1);
-                        const float n2 = __builtin_fmaf(8.0f * j, e2y, m2);
-    #pragma unroll 4
-                        for (int i = 0; i < NBX; i++) {
-                            const float worst = __builtin_fminf(__builtin_fminf(__builtin_fmaf(8.0f * i, e0x, n0),
-                                                                                __builtin_fmaf(8.0f * i, e1x, n1)),
-                                                                __builtin_fmaf(8.0f * i, e2x, n2));
-                            edge |= worst >= 0.0f ? 1u << (i + NBX * j) : 0u;
-                        }
-                    }
-                    // blocks the clamped box meets: columns floor((bx0 - qx0) / 8) .. floor((bx1 - qx0) / 8), rows
-                    // likewise, cut to the region (an empty box -- a rejected record, a lane without one --
-                    // gives an empty range)
-                    const int32_t ia = imax(isub((int32_t)r0.x, qx0) >> 3, 0), ib = imin(isub((int32_t)r0.y, qx0) >> 3, NBX - 1);
-                    const int32_t ja = imax(isub((int32_t)r0.z, qy0) >> 3, 0), jb = imin(isub((int32_t)r0.w, qy0) >> 3, NBY - 1);
-                    const uint32_t colbits = (ia <= ib && (int32_t)r0.x <= (int32_t)r0.y) ? (2u << ib) - (1u << ia) : 0u;
-                    uint32_t box = 0u;
-    #pragma unroll
-                    for (int j = 0; j < NBY; j++) box |= (j >= ja && j <= jb) ? colbits << (NBX * j) : 0u;
-                    lmask = edge & box;
-                }
-                // column pairs (block rows 0 / 1 of one block column) with a live block: what a visit iterates
-                // over -- the box's column range is already in the mask
-                lmask = (lmask | (lmask >> NBX)) & ((1u << NBX) - 1u);
-                const bool touch = lmask != 0u;
-                unsigned long long todo = __ballot(touch);
+                unsigned long long todo = __ballot(lmask != 0u);
                 while (todo) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(todo);
                     todo &= todo - 1ull;
-                    const int32_t bx0 = imax(bcast(r0.x, l), qx0), bx1 = imin(bcast(r0.y, l), qx0 + QUAD - 1);
-                    const int32_t by0 = imax(bcast(r0.z, l), qy0), by1 = imin(bcast(r0.w, l), qy0 + TILE_H - 1);
+                    const uint32_t boxx = (uint32_t)bcast(r0.x, l), boxy = (uint32_t)bcast(r0.y, l);
+                    const int32_t bx0 = imax((int32_t)(boxx & 0xFFFFu), qx0), bx1 = imin((int32_t)(boxx >> 16), qx0 + QUAD - 1);
+                    const int32_t by0 = imax((int32_t)(boxy & 0xFFFFu), qy0), by1 = imin((int32_t)(boxy >> 16), qy0 + TILE_H - 1);
                     const int32_t x0 = bcast(r1.x, l), y0 = bcast(r1.y, l);
                     const float z0 = __int_as_float(bcast(r2.z, l)), z1 = __int_as_float(bcast(r2.w, l));
                     const float z2 = __int_as_float(bcast(r3.x, l));
@@ -672,7 +669,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                         cols &= cols - 1u;
                         // the two pixels' current keys, requested before the arithmetic that decides
                         // whether they are needed (LDS latency hidden inside the wave)
-                        uint2 *slot_a = wkey + ((ib << 6) + (int32_t)lane), *slot_b = slot_a + (NBX << 6);
+                        uint2 *slot_a = SH ? wkey + (key_lane ^ ((uint32_t)ib << 3)) : wkey + ((ib << 6) + (int32_t)lane);
+                        uint2 *slot_b = slot_a + (SH ? 8 * TILE_W : NBX << 6);
                         const uint2 cur_a = *slot_a, cur_b = *slot_b;
                         const int32_t px = qx0 + ib * 8 + lx;
                         const bool inx = (uint32_t)isub(px, bx0) <= (uint32_t)isub(bx1, bx0);
@@ -730,6 +728,125 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                             }
                             if (wina) *slot_a = make_uint2(__float_as_uint(z.x), slot1);
                             if (winb) *slot_b = make_uint2(__float_as_uint(z.y), slot1);
+                        }
+                    }
+                }
+
+                if (SH && SCAN_ITEMS) {
+                    // ---- scan-line items of the round's small polygons --------------------------------
+                    // Items are numbered over the whole workgroup (thread order), 64 of them make a pass and
+                    // pass p belongs to wave p mod TILE_WAVES: every wave gets the same share wherever the
+                    // polygons sit in the bin.  A lane finds the record its item belongs to by a binary search
+                    // in the running sums and reads the record from LDS itself -- no broadcast at all -- then
+                    // tests the item's 8 pixels two at a time: (x, x + 1) in packed arithmetic with exactly
+                    // the operations of the visit above (scene.rs:178-187, 245-247, shader.rs:174).
+                    uint32_t incl = items;
+    #pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+                        if ((int)lane >= d) incl += up;
+                    }
+                    if (lane == 63u) s_wtot[wave] = incl;
+                    __syncthreads();  // (also: every wave is done with the previous round's sums)
+                    uint32_t before = 0u, total = 0u;
+    #pragma unroll
+                    for (int w = 0; w < TILE_WAVES; w++) {
+                        const uint32_t t = s_wtot[w];
+                        before += (uint32_t)w < wave ? t : 0u;
+                        total += t;
+                    }
+                    total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
+                    s_incl[tid] = before + incl;
+                    __syncthreads();
+                    for (uint32_t pass = wave; pass * 64u < total; pass += (uint32_t)TILE_WAVES) {
+                        const uint32_t item = pass * 64u + lane;
+                        const bool act = item < total;
+                        // owner = the first thread whose running sum exceeds the item's number
+                        uint32_t lo = 0u, hi = (uint32_t)TILE_THREADS - 1u;
+    #pragma unroll
+                        for (int i = 0; i < 6 + (TILE_WAVES == 4 ? 2 : TILE_WAVES == 8 ? 3 : 4); i++) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (s_incl[mid] > item)
+                                hi = mid;
+                            else
+                                lo = mid + 1u;
+                        }
+                        const uint32_t q = item - (lo ? s_incl[lo - 1u] : 0u);
+                        // thread lo = lane lo & 63 of wave lo >> 6 holds record j0 + lane * TILE_WAVES + wave
+                        const uint32_t rec = act ? j0 + (lo & 63u) * (uint32_t)TILE_WAVES + (lo >> 6) : 0u;
+                        const uint4 *const R = s_rec + mul24(rec, (uint32_t)P);
+                        const uint4 q0 = R[0], q1 = R[1], q2 = R[2];
+                        const uint2 q3 = *reinterpret_cast<const uint2 *>(R + 3);
+                        const float ryv = __uint_as_float(R[P - 1].w);
+                        // the item = the q-th live cell of the pair's mask: row `cell / 4` of the box inside the
+                        // tile, chunk `cell % 4` = pixels xs .. xs + 7 of that row (xs even)
+                        const PairBox ib = pair_box((int32_t)(q0.x & 0xFFFFu), (int32_t)(q0.x >> 16), (int32_t)(q0.y & 0xFFFFu),
+                                                    (int32_t)(q0.y >> 16), tile_x0, qy0);
+                        uint32_t cell;
+                        {
+                            const uint32_t nlo = (uint32_t)__popc(q0.z);
+                            const bool upper = q >= nlo;
+                            uint32_t w = upper ? q0.w : q0.z, k = upper ? q - nlo : q;
+                            cell = upper ? 32u : 0u;
+    #pragma unroll
+                            for (int sh = 16; sh >= 1; sh >>= 1) {
+                                const uint32_t below = (uint32_t)__popc(w & ((1u << sh) - 1u));
+                                const bool up = k >= below;
+                                k -= up ? below : 0u;
+                                w = up ? w >> sh : w;
+                                cell += up ? (uint32_t)sh : 0u;
+                            }
+                        }
+                        const int32_t py = ib.ay0 + (int32_t)(cell >> 2), xs = ib.xs + 8 * (int32_t)(cell & 3u);
+                        // pixels of the chunk inside the box, as a bit mask (bit i = pixel xs + i)
+                        const uint32_t first = (uint32_t)imax(isub(ib.ax0, xs), 0) & 7u, last = (uint32_t)imin(isub(ib.ax1, xs), 7) & 7u;  // (in 0..7 for a live item)
+                        const uint32_t inmask = act ? (2u << last) - (1u << first) : 0u;
+                        // the polygon's constants, orientation-normalised as above
+                        float a0 = __uint_as_float(q1.z), b0 = __uint_as_float(q1.w);
+                        float a1 = __uint_as_float(q2.x), b1 = __uint_as_float(q2.y);
+                        float cz = a0 * b1 - a1 * b0, yv = ryv;
+                        if (cz < 0.0f) {
+                            a0 = -a0; a1 = -a1; b0 = -b0; b1 = -b1;
+                            cz = -cz;
+                            yv = -yv;
+                        }
+                        const int32_t x0 = (int32_t)q1.x;
+                        const float bf = (float)isub((int32_t)q1.y, py);
+                        const f2 a1b = splat2(a1 * bf), a0b = splat2(a0 * bf);  // e.a1 * b2, e.a0 * b2 of edge_cross2
+                        Edge2 e;
+                        e.cz = splat2(cz);
+                        e.y = splat2(yv);
+                        const f2 z0 = splat2(__uint_as_float(q2.z)), z1 = splat2(__uint_as_float(q2.w));
+                        const f2 z2 = splat2(__uint_as_float(q3.x));
+                        const uint32_t tag = (((SHARED_MAX_POLYGONS - 1u) - q3.y) << 12) | (c0 + rec + 1u);
+                        const uint32_t yrel = (uint32_t)isub(py, qy0) & (uint32_t)(TILE_H - 1);
+                        const uint32_t xrel = (uint32_t)isub(xs, qx0) & (uint32_t)(TILE_W - 2);
+                        const uint32_t key_row = yrel * (uint32_t)TILE_W, key_sw = (yrel & 7u) << 3;
+    #pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t kx = (xrel + 2u * k) & (uint32_t)(TILE_W - 1);  // (a chunk may start up to 6 pixels from the tile's end: wraps, masked out)
+                            uint4 *const slot = reinterpret_cast<uint4 *>(wkey + (key_row + (kx ^ key_sw)));
+                            const uint4 cur = *slot;
+                            const int32_t px = xs + 2 * k;
+                            const f2 a2 = mk2((float)isub(x0, px), (float)isub(x0, px + 1));
+                            const f2 cx = a1b - a2 * splat2(b1), cy = a2 * splat2(b0) - a0b;
+                            const f2 rest = e.cz - (cx + cy);
+                            const bool hita = ((inmask >> (2 * k)) & 1u) && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
+                            const bool hitb = ((inmask >> (2 * k + 1)) & 1u) && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
+                            if (hita || hitb) {
+                                const Bary2 bar = barycentric2_for_compare(cx, cy, e);
+                                const f2 z = dot3_2(bar.x, bar.y, bar.z, z0, z1, z2);
+                                const unsigned long long ka = ((unsigned long long)depth_order_bits(z.x) << 32) | tag;
+                                const unsigned long long kb = ((unsigned long long)depth_order_bits(z.y) << 32) | tag;
+                                const unsigned long long ca_ = ((unsigned long long)cur.y << 32) | cur.x;
+                                const unsigned long long cb_ = ((unsigned long long)cur.w << 32) | cur.z;
+                                if (hita && ka > ca_)
+                                    __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot), ka, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (hitb && kb > cb_)
+                                    __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot) + 1, kb, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                     }
                 }
@@ -799,7 +916,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             uint32_t s1;
             if (SHARED && shared_tile) {
                 // tie-break word: low 12 bits = bin slot + 1 of a fragment, 0xFFF / 0 = the buffer's old content
-                const uint32_t f = s_key[key_slot<TILE_W>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].x & 0xFFFu;
+                const uint32_t f = s_key[shared_key_slot((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].x & 0xFFFu;
                 s1 = (f == 0xFFFu) ? 0u : f;
             } else {
                 s1 = s_key[key_slot<QUAD_COLUMN>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
@@ -1172,13 +1289,17 @@ int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_
     if (a.mesh.n_tri == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
-    const dim3 grid((a.mesh.n_tri + SETUP_POLYS - 1u) / SETUP_POLYS, group ? n_frames : 1u), block(64);
+    // polygons per wave: all 64 lanes when that still gives the machine a few thousand waves (the x64 grid's
+    // 321 408 polygons), fewer for small meshes (8: 5 022 polygons = 628 waves per frame)
+    uint32_t polys = SETUP_POLYS;
+    while (polys > 8u && (uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 2048u) polys >>= 1;
+    const dim3 grid((a.mesh.n_tri + polys - 1u) / polys, group ? n_frames : 1u), block(64);
 #define TR_SETUP_CASE(V)                                                                              \
     case V:                                                                                           \
         if (group)                                                                                    \
-            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group);       \
+            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group, polys);       \
         else                                                                                          \
-            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a);                 \
+            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a, polys);                 \
         break;
     switch (vs) {
     TR_SETUP_CASE(VS_DEFAULT)

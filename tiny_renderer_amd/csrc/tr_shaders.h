@@ -214,6 +214,123 @@ TR_HD bool covers_oriented(float cx, float cy, float cz_positive)
     return fminf(fminf(cx, cy), cz_positive - (cx + cy)) >= 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conservative coverage masks of a (polygon, tile) pair
+// ---------------------------------------------------------------------------------------------
+// The setup kernel stores, with every copy of a record it appends to a tile's bin, which parts of the
+// polygon's clamped box INSIDE THAT TILE can hold a fragment at all, so that the tile kernel never
+// evaluates the edge functions to find out (it used to classify 32 blocks per polygon and wave).
+// cross.x, cross.y and cross.z - (cross.x + cross.y) (scene.rs:178-187, 245-247) are linear in the
+// pixel, so their largest value over a cell is the value at the cell's origin plus the extent times the
+// positive part of the slope; a cell is dropped only when that maximum misses zero by more than a bound
+// (2^-21 of the operand magnitudes) on the f32 rounding of both this estimate and the per-pixel
+// evaluation -- a superset of the exact test's pixels is always kept (tests/test_emulation.py counts
+// violations on random and far-vertex soups; every GPU parity test runs through it).
+//
+//   SMALL pair (box inside the tile at most SCAN_MAX_CHUNKS 8-pixel chunks wide, counted from the even
+//   pixel at or left of its first column): 64 cells, bit 4 * row + chunk, row 0 = the box's first row
+//   inside the tile, chunk c = pixels xs + 8c .. xs + 8c + 7 of that row.
+//   LARGE pair: bits 0..15 of `lo` = the 8-pixel wide block columns of the tile (both block rows) with a
+//   live 8x8 block.
+constexpr int SCAN_MAX_CHUNKS = 4;
+
+struct PairBox {
+    int32_t ax0, ax1, ay0, ay1;  // the polygon's clamped box cut to the tile (absolute pixels)
+    int32_t xs;                  // even pixel at or left of ax0
+    int32_t nch;                 // 8-pixel chunks from xs that reach ax1
+};
+
+TR_HD PairBox pair_box(int32_t bx0, int32_t bx1, int32_t by0, int32_t by1, int32_t tile_x0, int32_t tile_y0)
+{
+    PairBox b;
+    b.ax0 = imax(bx0, tile_x0);
+    b.ax1 = imin(bx1, tile_x0 + TILE_W - 1);
+    b.ay0 = imax(by0, tile_y0);
+    b.ay1 = imin(by1, tile_y0 + TILE_H - 1);
+    b.xs = b.ax0 & ~1;
+    b.nch = (isub(b.ax1, b.xs) >> 3) + 1;
+    return b;
+}
+
+TR_HD float fma_est(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return fmaf(a, b, c);
+#endif
+}
+
+TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, uint32_t &lo, uint32_t &hi)
+{
+    const PairBox pb = pair_box(r.bx0, r.bx1, r.by0, r.by1, tile_x0, tile_y0);
+    lo = hi = 0u;
+    if (pb.ax0 > pb.ax1 || pb.ay0 > pb.ay1) return;
+    // orientation-normalised edge constants (cross.z > 0), as the tile kernel uses them
+    float a0 = (float)isub(r.x1, r.x0), a1 = (float)isub(r.x2, r.x0);
+    float b0 = (float)isub(r.y1, r.y0), b1 = (float)isub(r.y2, r.y0);
+    float cz = a0 * b1 - a1 * b0;
+    if (cz < 0.0f) {
+        a0 = -a0; a1 = -a1; b0 = -b0; b1 = -b1;
+        cz = -cz;
+    }
+    const bool small = pb.nch <= SCAN_MAX_CHUNKS;
+    const int32_t org_x = small ? pb.xs : tile_x0, org_y = small ? pb.ay0 : tile_y0;
+    const float ox = (float)isub(r.x0, org_x), oy = (float)isub(r.y0, org_y);
+    const float e0x = b1, e0y = -a1, e1x = -b0, e1y = a0, e2x = b0 - b1, e2y = a1 - a0;
+    const float e0 = a1 * oy - ox * b1, e1 = ox * b0 - a0 * oy;
+    const float e2 = cz - (e0 + e1);
+    const float margin = 4.76837158e-7f /* 2^-21 */ *
+                         (((fabsf(a1) + fabsf(a0)) * (fabsf(oy) + (float)TILE_H) +
+                           (fabsf(b1) + fabsf(b0)) * (fabsf(ox) + (small ? 8.0f * SCAN_MAX_CHUNKS : (float)TILE_W))) + cz);
+    const float px0 = fmaxf(e0x, 0.0f), px1 = fmaxf(e1x, 0.0f), px2 = fmaxf(e2x, 0.0f);
+    if (small) {
+        const float m0 = e0 + (7.0f * px0 + margin), m1 = e1 + (7.0f * px1 + margin), m2 = e2 + (7.0f * px2 + 2.0f * margin);
+        const int32_t rows = pb.ay1 - pb.ay0 + 1;
+        for (int j = 0; j < TILE_H; j++) {
+            const float n0 = fma_est((float)j, e0y, m0), n1 = fma_est((float)j, e1y, m1), n2 = fma_est((float)j, e2y, m2);
+            uint32_t bits = 0u;
+            for (int c = 0; c < SCAN_MAX_CHUNKS; c++) {
+                const float worst = fminf(fminf(fma_est(8.0f * c, e0x, n0), fma_est(8.0f * c, e1x, n1)), fma_est(8.0f * c, e2x, n2));
+                bits |= (worst >= 0.0f && c < pb.nch && j < rows) ? 1u << c : 0u;
+            }
+            if (j < 8)
+                lo |= bits << (4 * j);
+            else
+                hi |= bits << (4 * (j - 8));
+        }
+    } else {
+        const float py0 = fmaxf(e0y, 0.0f), py1 = fmaxf(e1y, 0.0f), py2 = fmaxf(e2y, 0.0f);
+        const float m0 = e0 + (7.0f * (px0 + py0) + margin), m1 = e1 + (7.0f * (px1 + py1) + margin);
+        const float m2 = e2 + (7.0f * (px2 + py2) + 2.0f * margin);
+        // block columns / rows the box meets
+        const int32_t ia = isub(pb.ax0, tile_x0) >> 3, ib = isub(pb.ax1, tile_x0) >> 3;
+        const int32_t ja = isub(pb.ay0, tile_y0) >> 3, jb = isub(pb.ay1, tile_y0) >> 3;
+        for (int j = 0; j < TILE_H / 8; j++) {
+            const float n0 = fma_est(8.0f * j, e0y, m0), n1 = fma_est(8.0f * j, e1y, m1), n2 = fma_est(8.0f * j, e2y, m2);
+            for (int i = 0; i < TILE_W / 8; i++) {
+                const float worst = fminf(fminf(fma_est(8.0f * i, e0x, n0), fma_est(8.0f * i, e1x, n1)), fma_est(8.0f * i, e2x, n2));
+                lo |= (worst >= 0.0f && i >= ia && i <= ib && j >= ja && j <= jb) ? 1u << i : 0u;
+            }
+        }
+    }
+}
+
+// Block columns of the tile (8 pixels wide, bit i) that can hold a fragment of a pair, from its masks:
+// a large pair's `lo` as it is; a small pair's from the chunk columns of its cells (a chunk starts at an
+// even pixel and may straddle two block columns).
+TR_HD uint32_t pair_block_columns(uint32_t lo, uint32_t hi, const PairBox &pb, int32_t tile_x0)
+{
+    if (pb.nch > SCAN_MAX_CHUNKS) return lo & 0xFFFFu;
+    uint32_t c = lo | hi;
+    c |= c >> 16;
+    c |= c >> 8;
+    c = (c | (c >> 4)) & 0xFu;  // chunk columns with a live cell
+    const uint32_t first = (uint32_t)isub(pb.xs, tile_x0);
+    const uint32_t cols = c << (first >> 3);
+    return (cols | ((first & 7u) ? cols << 1 : 0u)) & 0xFFFFu;
+}
+
 // RN(1 / cross.z) of a polygon record: computed once per polygon by the setup kernel, carried
 // in the record's spare word.
 TR_HD float record_recip(const RasterRec &r) { return 1.0f / edge_setup(r).cz; }
