@@ -427,6 +427,10 @@ constexpr uint32_t SHARED_MAX_POLYGONS = 1u << 20, SHARED_MAX_SLOTS = 4093u;
 #define TR_SCAN_ITEMS 1
 #endif
 constexpr bool SCAN_ITEMS = TR_SCAN_ITEMS != 0;
+// Measurement builds only (wrong frames): leave a phase out to time the others (profiles/r03_notes.md)
+#ifndef TR_DBG_SKIP
+#define TR_DBG_SKIP 0  // 1: no fragment stage, 2: no item passes, 4: no visits
+#endif
 __device__ __forceinline__ uint32_t depth_order_bits(float z)
 {
     uint32_t b = __float_as_uint(z);
@@ -493,6 +497,12 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     if (tid == 0u) a.tile_count_next[tile] = 0u;
     if (work_index == 0u && tid < 2u * (uint32_t)ORDER_BUCKETS)
         a.tile_count_next[a.frame.ntx * a.frame.nty + tid] = 0u;  // k_order's bucket sizes and cursors
+    if ((TR_DBG_SKIP & 8) && n == 0u) return;
+    if (TR_DBG_SKIP & 16) return;                       // every workgroup: dispatch + one load
+    if ((TR_DBG_SKIP & 32) && n != 0u) {                // busy tiles: stores only
+        write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W, (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, true);
+        return;
+    }
     if (n == 0u) {
         if (a.fresh) {
             // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
@@ -633,7 +643,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     lcz = -lcz;
                     lry = -lry;
                 }
-                unsigned long long todo = __ballot(lmask != 0u);
+                unsigned long long todo = (TR_DBG_SKIP & 4) ? 0ull : __ballot(lmask != 0u);
                 while (todo) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(todo);
                     todo &= todo - 1ull;
@@ -758,7 +768,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
                     s_incl[tid] = before + incl;
                     __syncthreads();
-                    for (uint32_t pass = wave; pass * 64u < total; pass += (uint32_t)TILE_WAVES) {
+                    for (uint32_t pass = wave; !(TR_DBG_SKIP & 2) && pass * 64u < total; pass += (uint32_t)TILE_WAVES) {
                         const uint32_t item = pass * 64u + lane;
                         const bool act = item < total;
                         // owner = the first thread whose running sum exceeds the item's number
@@ -889,18 +899,185 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const uint32_t Wu = (uint32_t)W, W3 = 3u * (uint32_t)W;
     const bool col_live = px < W;
 
-    // The loop exists twice: for bins that stay resident in LDS (nearly all) and for the rare larger
-    // ones, whose survivors' records come from global memory -- a run-time choice inside the loop
-    // cost a dozen register moves per step where the two paths merge.
-    // ... and in two flavours of the closure call: PAIR runs the two-pixel closures (tr_shaders.h) and
-    // returns the steps in which a surviving pixel left their guarded range; those steps are then run
-    // again, whole, with the plain closures (every store of a step is repeated, so the second run
-    // simply overwrites the first).  Keeping the plain closures out of the fast loop's body matters:
-    // inline, as the fallback of each step, their registers were live across the fast path and cost
-    // 5-9 % (spills) although they almost never ran.
+    // Reads a pixel's key and returns the bin slot + 1 of its survivor (0: none)
+    auto survivor_slot = [&](uint32_t sx, uint32_t sy) -> uint32_t {
+        if (SHARED && shared_tile) {
+            // tie-break word: low 12 bits = bin slot + 1 of a fragment, 0xFFF / 0 = the buffer's old content
+            const uint32_t f = s_key[shared_key_slot((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)].x & 0xFFFu;
+            return (f == 0xFFFu) ? 0u : f;
+        }
+        return s_key[key_slot<QUAD_COLUMN>((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)].y;
+    };
+    // Two pixels of a lane through the fragment stage, each against its own polygon: pixel u at (pxs[u], pys[u]),
+    // survivor in bin slot wslot[u] if won[u].  Lanes without a survivor run the same loads on record 0 and
+    // discard the result, so the code is branch-free.  RESIDENT: the bin's records are in LDS (nearly always);
+    // PAIR: the two-pixel closures (tr_shaders.h) -- returns true when a surviving pixel left their guarded
+    // range anywhere in the wave (the caller then runs the step again with the plain closures; keeping those
+    // out of the fast loop's body matters: inline, as the fallback of each step, their registers were live
+    // across the fast path and cost 5-9 % although they almost never ran).
+    auto shade_two = [&](auto in_lds, auto pair_tag, const int32_t (&pxs)[2], const int32_t (&pys)[2], const bool (&won)[2],
+                         const uint32_t (&wslot)[2], float (&zout)[2], uint32_t (&rgb)[2], uint32_t (&tri)[2]) -> bool {
+        constexpr bool RESIDENT = decltype(in_lds)::value;
+        constexpr bool PAIR = decltype(pair_tag)::value;
+        bool redo = false;
+        // The two survivors' records.  Pieces 1..TOP-1 (raster part, uv and, for the 6-piece record,
+        // everything else) are taken for both pixels at once; the darboux record's further 16
+        // varyings per pixel are fetched when that pixel's closure runs, one pixel after the other,
+        // so that 32 fewer registers are live (123 -> under 96: a fifth wave per SIMD).
+        constexpr int TOP = P < 6 ? P : 6;
+        uint4 qa[TOP], qb[TOP];
+        const uint4 *const ra = RESIDENT ? s_rec + mul24(wslot[0], (uint32_t)P) : bin + (size_t)wslot[0] * P;
+        const uint4 *const rb = RESIDENT ? s_rec + mul24(wslot[1], (uint32_t)P) : bin + (size_t)wslot[1] * P;
+#pragma unroll
+        for (int i = 1; i < TOP; i++) {
+            qa[i] = ra[i];
+            qb[i] = rb[i];
+        }
+        const uint32_t rya = P > TOP ? ra[P - 1].w : qa[TOP - 1].w, ryb = P > TOP ? rb[P - 1].w : qb[TOP - 1].w;
+        // to_barycentric_coord for both pixels (each against its own polygon)
+        Edge2 e;
+        e.a0 = mk2(__uint_as_float(qa[1].z), __uint_as_float(qb[1].z));
+        e.a1 = mk2(__uint_as_float(qa[2].x), __uint_as_float(qb[2].x));
+        e.b0 = mk2(__uint_as_float(qa[1].w), __uint_as_float(qb[1].w));
+        e.b1 = mk2(__uint_as_float(qa[2].y), __uint_as_float(qb[2].y));
+        e.cz = e.a0 * e.b1 - e.a1 * e.b0;
+        e.y = mk2(__uint_as_float(rya), __uint_as_float(ryb));
+        const f2 a2 = mk2((float)isub((int32_t)qa[1].x, pxs[0]), (float)isub((int32_t)qb[1].x, pxs[1]));
+        const f2 b2 = mk2((float)isub((int32_t)qa[1].y, pys[0]), (float)isub((int32_t)qb[1].y, pys[1]));
+        f2 cx, cy;
+        edge_cross2(e, a2, b2, cx, cy);
+        const Bary2 bar = barycentric2(cx, cy, e);
+        const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
+                            mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
+                            mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
+        uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
+        if (!DEPTH) {
+            // uv = vertex_uvs * bar (2x3 gemv), both pixels
+            f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
+            f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
+            uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
+            vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
+            uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
+            vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
+            if (FS == FS_DEFAULT || FS == FS_PHONG) {
+                // shader.rs:318-333 / 386-401 for both pixels at once: texel, diffuse term,
+                // color_blend(c, 0, t) = (t * c + (1 - t) * 0.0) as u8 per channel
+                const uint32_t ta = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
+                const uint32_t tb = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
+                f2 t = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
+                if (FS == FS_PHONG)
+                    t = dot3_2(bar.x, bar.y, bar.z, t, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
+                               mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
+                const f2 k = (splat2(1.0f) - t) * splat2(0.0f);
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+                    ca |= f32_to_u8(v.x) << (8 * ch);
+                    cb |= f32_to_u8(v.y) << (8 * ch);
+                }
+            } else {
+                // one pixel's closure after the other's (interleaved they need twice the registers)
+                auto closure = [&](const uint4 (&q)[TOP], const uint4 *rec, vec3 b, float u_, float v_, int32_t px_, int32_t py_,
+                                   float z_, uint32_t &e_) {
+                    float v[VARY_STRIDE];
+                    v[0] = __uint_as_float(q[3].z); v[1] = __uint_as_float(q[3].w);
+#pragma unroll
+                    for (int i = 4; i < P; i++) {
+                        const uint4 piece = i < TOP ? q[i] : rec[i];
+                        v[4 * i - 14] = __uint_as_float(piece.x); v[4 * i - 13] = __uint_as_float(piece.y);
+                        v[4 * i - 12] = __uint_as_float(piece.z); v[4 * i - 11] = __uint_as_float(piece.w);
+                    }
+                    return fragment_color<FS>(a.u, a.tex, v, b, u_, v_, (uint32_t)px_, (uint32_t)py_, z_, a.shadow,
+                                              (uint32_t)W, (uint32_t)H, e_, a.sclean);
+                };
+                if (PAIR) {
+                    // both pixels through the closure together in packed arithmetic with shared
+                    // reciprocals (tr_shaders.h, fragment_color_pair); a step in which a surviving pixel's
+                    // operands leave the range that form is proven on is run again with the plain
+                    // closure (rare: exact zeros among the normalised components, a degenerate basis)
+                    auto vary2 = [&](int k) -> f2 {
+                        const int i = k < 2 ? 3 : (k + 14) / 4, c = k < 2 ? k + 2 : (k + 14) % 4;
+                        const uint4 pa = i < TOP ? qa[i] : ra[i], pb = i < TOP ? qb[i] : rb[i];
+                        const uint32_t wa = c == 0 ? pa.x : c == 1 ? pa.y : c == 2 ? pa.z : pa.w;
+                        const uint32_t wb = c == 0 ? pb.x : c == 1 ? pb.y : c == 2 ? pb.z : pb.w;
+                        return mk2(__uint_as_float(wa), __uint_as_float(wb));
+                    };
+                    bool bad_a, bad_b;
+                    vec3p barp;
+                    barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
+                    fragment_color_pair<FS>(a.u, a.tex, vary2, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
+                    if (__any((bad_a && won[0]) || (bad_b && won[1]))) {
+                        redo = true;
+                        ea = eb = 0u;  // the second run reports this step's lookups
+                    }
+                } else {
+                    ca = closure(qa, ra, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, pxs[0], pys[0], z.x, ea);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cb = closure(qb, rb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, pxs[1], pys[1], z.y, eb);
+                }
+            }
+        }
+        uint32_t err = 0u;
+        if (won[0]) {
+            zout[0] = z.x;
+            rgb[0] = ca;
+            tri[0] = qa[3].y;
+            err |= ea;
+        }
+        if (won[1]) {
+            zout[1] = z.y;
+            rgb[1] = cb;
+            tri[1] = qb[3].y;
+            err |= eb;
+        }
+        if (err) atomicOr(a.err, err);
+        return redo;
+    };
+
+    // One pixel of a lane to memory: row `row` of the strip (this lane's column hx), `live` = inside frame and band,
+    // `put` = its depth (and winner word) changes.  Depth goes out straight from registers as whole 128-byte lines;
+    // colour is packed to dwords with two lane permutes and stored flipped (scene.rs:92-97 folded in).
+    auto store_pixel = [&](int32_t row, int32_t py_, bool live, bool won, float zv, uint32_t rgbv, uint32_t triv, bool with_winner) {
+        const uint32_t zoff = mul24((uint32_t)row, Wu) + (uint32_t)hx;
+        const uint32_t coff = mul24((uint32_t)(STRIP_ROWS - 1 - row), W3);  // the row's first byte
+        if (!DEPTH && !a.fresh && live && !won) {
+            // untouched pixel of an accumulate render: its colour may share a dword with a
+            // touched neighbour, so fetch it
+            const uint8_t *old = fb_strip + (coff + 3u * (uint32_t)hx);
+            rgbv = pack_rgb(old[0], old[1], old[2]);
+        }
+        // depth: only pixels that changed (or every live pixel of a fresh tile)
+        const bool put = live && (won || zfresh);
+        if (put) depth_strip[zoff] = zv;
+        if (!DEPTH) {
+            if (winner_strip && put && with_winner) winner_strip[zoff] = triv;
+            if (a.aligned4) {
+                // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
+                // on, topped up from pixel p0+1
+                const uint32_t j = (uint32_t)hx;
+                const uint32_t p0 = (4u * j) / 3u, o = (4u * j) % 3u;
+                const uint32_t c0 = (uint32_t)__shfl((int)rgbv, (int)(half_base + (p0 & 31u)), 64);
+                const uint32_t c1 = (uint32_t)__shfl((int)rgbv, (int)(half_base + ((p0 + 1u) & 31u)), 64);
+                const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
+                const bool row_live = py_ >= a.frame.band_y0 && py_ < a.frame.band_y1;
+                if (j < 24u && row_live && (sx0 * 3 + (int32_t)(4u * j)) < W * 3)
+                    *reinterpret_cast<uint32_t *>(fb_strip + (coff + 4u * j)) = dw;
+            } else if (put) {
+                uint8_t *p = fb_strip + (coff + 3u * (uint32_t)hx);
+                p[0] = (uint8_t)(rgbv & 0xFFu);
+                p[1] = (uint8_t)((rgbv >> 8) & 0xFFu);
+                p[2] = (uint8_t)((rgbv >> 16) & 0xFFu);
+            }
+        }
+    };
+
+    // ---- row-major form: lane = x within a 32-pixel row; a step covers four rows, each lane carrying the
+    // two pixels (x, 4s + half) and (x, 4s + 2 + half) through the fragment stage and straight to memory.
+    // Exists for bins that stay resident in LDS and for the rare larger ones, whose survivors' records come
+    // from global memory -- a run-time choice inside the loop cost a dozen register moves per step where the
+    // two paths merge.  Returns the steps to run again with the plain closures (every store of a step is
+    // repeated, so the second run simply overwrites the first).
     auto shade_steps = [&](auto in_lds, auto pair_tag, uint32_t step_mask) -> uint32_t {
-    constexpr bool RESIDENT = decltype(in_lds)::value;
-    constexpr bool PAIR = decltype(pair_tag)::value;
     uint32_t redo = 0u;
 #pragma unroll 1
     for (int32_t sstep = 0; sstep < NSTEP; sstep++) {
@@ -913,170 +1090,22 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             row[u] = sstep * 4 + u * 2 + hrow;  // within the strip
             py[u] = sy0 + row[u];
             live[u] = col_live && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
-            uint32_t s1;
-            if (SHARED && shared_tile) {
-                // tie-break word: low 12 bits = bin slot + 1 of a fragment, 0xFFF / 0 = the buffer's old content
-                const uint32_t f = s_key[shared_key_slot((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].x & 0xFFFu;
-                s1 = (f == 0xFFFu) ? 0u : f;
-            } else {
-                s1 = s_key[key_slot<QUAD_COLUMN>((uint32_t)(strip_x + hx), (uint32_t)(strip_y + row[u]))].y;
-            }
+            const uint32_t s1 = survivor_slot((uint32_t)hx, (uint32_t)row[u]);
             won[u] = live[u] && s1 != 0u;
             wslot[u] = won[u] ? s1 - 1u : 0u;
         }
         uint32_t tri[2] = { NO_WINNER, NO_WINNER }, rgb[2] = { 0u, 0u };
         float zout[2] = { bits_f32(TR_F32_MIN_BITS), bits_f32(TR_F32_MIN_BITS) };
-        if (__any(won[0] || won[1])) {
-            // The two survivors' records.  Pieces 1..TOP-1 (raster part, uv and, for the 6-piece record,
-            // everything else) are taken for both pixels at once; the darboux record's further 16
-            // varyings per pixel are fetched when that pixel's closure runs, one pixel after the other,
-            // so that 32 fewer registers are live (123 -> under 96: a fifth wave per SIMD).
-            constexpr int TOP = P < 6 ? P : 6;
-            uint4 qa[TOP], qb[TOP];
-            const uint4 *const ra = RESIDENT ? s_rec + mul24(wslot[0], (uint32_t)P) : bin + (size_t)wslot[0] * P;
-            const uint4 *const rb = RESIDENT ? s_rec + mul24(wslot[1], (uint32_t)P) : bin + (size_t)wslot[1] * P;
-#pragma unroll
-            for (int i = 1; i < TOP; i++) {
-                qa[i] = ra[i];
-                qb[i] = rb[i];
-            }
-            const uint32_t rya = P > TOP ? ra[P - 1].w : qa[TOP - 1].w, ryb = P > TOP ? rb[P - 1].w : qb[TOP - 1].w;
-            // to_barycentric_coord for both pixels (each against its own polygon)
-            Edge2 e;
-            e.a0 = mk2(__uint_as_float(qa[1].z), __uint_as_float(qb[1].z));
-            e.a1 = mk2(__uint_as_float(qa[2].x), __uint_as_float(qb[2].x));
-            e.b0 = mk2(__uint_as_float(qa[1].w), __uint_as_float(qb[1].w));
-            e.b1 = mk2(__uint_as_float(qa[2].y), __uint_as_float(qb[2].y));
-            e.cz = e.a0 * e.b1 - e.a1 * e.b0;
-            e.y = mk2(__uint_as_float(rya), __uint_as_float(ryb));
-            const f2 a2 = mk2((float)isub((int32_t)qa[1].x, px), (float)isub((int32_t)qb[1].x, px));
-            const f2 b2 = mk2((float)isub((int32_t)qa[1].y, py[0]), (float)isub((int32_t)qb[1].y, py[1]));
-            f2 cx, cy;
-            edge_cross2(e, a2, b2, cx, cy);
-            const Bary2 bar = barycentric2(cx, cy, e);
-            const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
-                                mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
-                                mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
-            uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
-            if (!DEPTH) {
-                // uv = vertex_uvs * bar (2x3 gemv), both pixels
-                f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
-                f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
-                uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
-                vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
-                uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
-                vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
-                if (FS == FS_DEFAULT || FS == FS_PHONG) {
-                    // shader.rs:318-333 / 386-401 for both pixels at once: texel, diffuse term,
-                    // color_blend(c, 0, t) = (t * c + (1 - t) * 0.0) as u8 per channel
-                    const uint32_t ta = fetch_texel(a.tex, 0, 0, uu.x, vv.x, ea);
-                    const uint32_t tb = fetch_texel(a.tex, 0, 0, uu.y, vv.y, eb);
-                    f2 t = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
-                    if (FS == FS_PHONG)
-                        t = dot3_2(bar.x, bar.y, bar.z, t, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
-                                   mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
-                    const f2 k = (splat2(1.0f) - t) * splat2(0.0f);
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
-                        ca |= f32_to_u8(v.x) << (8 * ch);
-                        cb |= f32_to_u8(v.y) << (8 * ch);
-                    }
-                } else {
-                    // one pixel's closure after the other's (interleaved they need twice the registers)
-                    auto closure = [&](const uint4 (&q)[TOP], const uint4 *rec, vec3 b, float u_, float v_, int32_t py_,
-                                       float z_, uint32_t &e_) {
-                        float v[VARY_STRIDE];
-                        v[0] = __uint_as_float(q[3].z); v[1] = __uint_as_float(q[3].w);
-#pragma unroll
-                        for (int i = 4; i < P; i++) {
-                            const uint4 piece = i < TOP ? q[i] : rec[i];
-                            v[4 * i - 14] = __uint_as_float(piece.x); v[4 * i - 13] = __uint_as_float(piece.y);
-                            v[4 * i - 12] = __uint_as_float(piece.z); v[4 * i - 11] = __uint_as_float(piece.w);
-                        }
-                        return fragment_color<FS>(a.u, a.tex, v, b, u_, v_, (uint32_t)px, (uint32_t)py_, z_, a.shadow,
-                                                  (uint32_t)W, (uint32_t)H, e_, a.sclean);
-                    };
-                    if (PAIR) {
-                        // both pixels through the closure together in packed arithmetic with shared
-                        // reciprocals (tr_shaders.h, fragment_color_pair); a step in which a surviving pixel's
-                        // operands leave the range that form is proven on is run again with the plain
-                        // closure (rare: exact zeros among the normalised components, a degenerate basis)
-                        auto vary2 = [&](int k) -> f2 {
-                            const int i = k < 2 ? 3 : (k + 14) / 4, c = k < 2 ? k + 2 : (k + 14) % 4;
-                            const uint4 pa = i < TOP ? qa[i] : ra[i], pb = i < TOP ? qb[i] : rb[i];
-                            const uint32_t wa = c == 0 ? pa.x : c == 1 ? pa.y : c == 2 ? pa.z : pa.w;
-                            const uint32_t wb = c == 0 ? pb.x : c == 1 ? pb.y : c == 2 ? pb.z : pb.w;
-                            return mk2(__uint_as_float(wa), __uint_as_float(wb));
-                        };
-                        bool bad_a, bad_b;
-                        vec3p barp;
-                        barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
-                        fragment_color_pair<FS>(a.u, a.tex, vary2, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
-                        if (__any((bad_a && won[0]) || (bad_b && won[1]))) {
-                            redo |= 1u << sstep;
-                            ea = eb = 0u;  // the second run reports this step's lookups
-                        }
-                    } else {
-                        ca = closure(qa, ra, make3(bar.x.x, bar.y.x, bar.z.x), uu.x, vv.x, py[0], z.x, ea);
-                        __builtin_amdgcn_sched_barrier(0);
-                        cb = closure(qb, rb, make3(bar.x.y, bar.y.y, bar.z.y), uu.y, vv.y, py[1], z.y, eb);
-                    }
-                }
-            }
-            uint32_t err = 0u;
-            if (won[0]) {
-                zout[0] = z.x;
-                rgb[0] = ca;
-                tri[0] = qa[3].y;
-                err |= ea;
-            }
-            if (won[1]) {
-                zout[1] = z.y;
-                rgb[1] = cb;
-                tri[1] = qb[3].y;
-                err |= eb;
-            }
-            if (err) atomicOr(a.err, err);
+        if (!(TR_DBG_SKIP & 1) && __any(won[0] || won[1])) {
+            const int32_t pxs[2] = { px, px };
+            if (shade_two(in_lds, pair_tag, pxs, py, won, wslot, zout, rgb, tri)) redo |= 1u << sstep;
         }
-
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t zoff = mul24((uint32_t)row[u], Wu) + (uint32_t)hx;
-            const uint32_t coff = mul24((uint32_t)(STRIP_ROWS - 1 - row[u]), W3);  // the row's first byte
-            if (!DEPTH && !a.fresh && live[u] && !won[u]) {
-                // untouched pixel of an accumulate render: its colour may share a dword with a
-                // touched neighbour, so fetch it
-                const uint8_t *old = fb_strip + (coff + 3u * (uint32_t)hx);
-                rgb[u] = pack_rgb(old[0], old[1], old[2]);
-            }
-            // depth: only pixels that changed (or every live pixel of a fresh tile)
-            const bool put = live[u] && (won[u] || zfresh);
-            if (put) depth_strip[zoff] = zout[u];
-            if (!DEPTH) {
-                if (winner_strip && put) winner_strip[zoff] = tri[u];
-                if (a.aligned4) {
-                    // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
-                    // on, topped up from pixel p0+1
-                    const uint32_t j = (uint32_t)hx;
-                    const uint32_t p0 = (4u * j) / 3u, o = (4u * j) % 3u;
-                    const uint32_t c0 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + (p0 & 31u)), 64);
-                    const uint32_t c1 = (uint32_t)__shfl((int)rgb[u], (int)(half_base + ((p0 + 1u) & 31u)), 64);
-                    const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
-                    const bool row_live = py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
-                    if (j < 24u && row_live && (sx0 * 3 + (int32_t)(4u * j)) < W * 3)
-                        *reinterpret_cast<uint32_t *>(fb_strip + (coff + 4u * j)) = dw;
-                } else if (put) {
-                    uint8_t *p = fb_strip + (coff + 3u * (uint32_t)hx);
-                    p[0] = (uint8_t)(rgb[u] & 0xFFu);
-                    p[1] = (uint8_t)((rgb[u] >> 8) & 0xFFu);
-                    p[2] = (uint8_t)((rgb[u] >> 16) & 0xFFu);
-                }
-            }
-        }
+        for (int u = 0; u < 2; u++) store_pixel(row[u], py[u], live[u], won[u], zout[u], rgb[u], tri[u], true);
     }
     return redo;
     };
+
     constexpr uint32_t ALL_STEPS = (1u << NSTEP) - 1u;
     constexpr bool HAS_PAIR = has_pair_closure(FS);
     uint32_t redo;
