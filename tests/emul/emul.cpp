@@ -225,11 +225,12 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
                 // what k_setup stores with this (polygon, tile) pair: the cells / block columns that can hold a
                 // fragment.  Pixels outside them are skipped, as the tile kernel skips them; a covered pixel
                 // found there is a violation of the masks' conservativeness (counted, and the frame is wrong).
-                uint32_t mlo = 0, mhi = 0;
-                pair_masks(r, tile_x0, tile_y0, mlo, mhi);
+                uint32_t mlo = 0, mhi = 0, blo = 0, bhi = 0;
+                pair_masks(r, tile_x0, tile_y0, true, mlo, mhi);    // a pass whose tile kernel runs the shared form
+                pair_masks(r, tile_x0, tile_y0, false, blo, bhi);   // ... owns columns: block columns for every pair
                 const PairBox pb = pair_box(r.bx0, r.bx1, r.by0, r.by1, tile_x0, tile_y0);
                 const bool small_pair = pb.nch <= SCAN_MAX_CHUNKS;
-                const uint32_t cols = pair_block_columns(mlo, mhi, pb, tile_x0);
+                const uint32_t cols = pair_block_columns(mlo, mhi, true, pb, tile_x0) & pair_block_columns(blo, bhi, false, pb, tile_x0);
                 if (small_pair) {
                     g_mask_cells_live += (uint64_t)(__builtin_popcount(mlo) + __builtin_popcount(mhi));
                     g_mask_cells_box += (uint64_t)(pb.nch * (pb.ay1 - pb.ay0 + 1));

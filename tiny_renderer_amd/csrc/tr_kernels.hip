@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "tr_kernels.h"
@@ -48,20 +50,35 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 // k_setup
 // -----------------------------------------------------------------------------------------
 constexpr uint32_t SETUP_POLYS = 64;  // polygons per 64-lane workgroup of k_setup, at most (launch_setup chooses)
+// what pair_masks needs of a polygon: clamped box and raster coordinates (40 bytes)
+struct SetupRaster {
+    int32_t bx0, bx1, by0, by1, x0, y0, x1, y1, x2, y2;
+};
+constexpr uint32_t SETUP_LDS_BUDGET = 9728;
+constexpr uint32_t setup_lds_bytes(uint32_t polys, uint32_t pieces) { return polys * (pieces * 16u + (uint32_t)sizeof(SetupRaster)) + 4u * 64u * 4u; }
 
 template <int VS>
 __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, uint32_t polys)
 {
     constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    __shared__ uint4 s_rec[SETUP_POLYS * P];
-    __shared__ RasterRec s_rast[SETUP_POLYS];
-    __shared__ int32_t s_excl[64], s_tx0[64], s_ty0[64], s_ntx[64];
+    // LDS, sized by the launch for `polys` polygons (setup_lds_bytes): records, raster coordinates for the pair
+    // masks, the binning's per-lane tables.  Kept under 10 KiB: that is what six resident workgroups of the tile
+    // kernel leave free on a compute unit, and a setup workgroup that does not fit beside them displaces one
+    // (11 KiB per workgroup cost the 4096^2 tile kernel 7 %).
+    extern __shared__ uint4 s_setup[];
+    uint4 *const s_rec = s_setup;
+    SetupRaster *const s_rast = reinterpret_cast<SetupRaster *>(s_setup + polys * P);
+    int32_t *const s_excl = reinterpret_cast<int32_t *>(s_rast + polys), *const s_tx0 = s_excl + 64, *const s_ty0 = s_tx0 + 64,
+                   *const s_ntx = s_ty0 + 64;
 
     // Lane = polygon for the vertex stage (the first `polys` lanes: a small mesh is spread over more waves
     // than it has sixty-fourths, because the wave with the most (polygon, tile) pairs is the kernel's
     // critical path and a lone frame waits for it); all 64 lanes then share the binning below.
     const uint32_t lane = threadIdx.x;
     const uint32_t t = block * polys + lane;
+    // the 16 words behind this pass's counters (k_order's list lengths): their
+    // last readers -- the tile kernel of the pass that had the set before -- are done (the host orders that)
+    if (block == 0u && lane < 16u) a.tile_count[a.frame.ntx * a.frame.nty + lane] = 0u;
 
     int32_t tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
     uint32_t err = 0;
@@ -95,7 +112,10 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, u
             // spare last word (varying 9 / 21 is unused): RN(1 / cross.z), the one IEEE division
             // per polygon; k_tile derives every per-pixel quotient from it (tr_math.h div_by)
             o[P - 1].w = __float_as_uint(record_recip(r));
-            s_rast[lane] = r;
+            SetupRaster sr;
+            sr.bx0 = r.bx0; sr.bx1 = r.bx1; sr.by0 = r.by0; sr.by1 = r.by1;
+            sr.x0 = r.x0; sr.y0 = r.y0; sr.x1 = r.x1; sr.y1 = r.y1; sr.x2 = r.x2; sr.y2 = r.y2;
+            s_rast[lane] = sr;
             tx0 = r.bx0 / TILE_W;
             ty0 = r.by0 / TILE_H;
             ntx = r.bx1 / TILE_W - tx0 + 1;
@@ -163,7 +183,11 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, u
                 // which cells (small pair) or block columns (large pair) of the box inside THIS tile can hold
                 // a fragment: the tile kernel evaluates no edge function to find its work
                 uint4 head = src[0];
-                pair_masks(s_rast[own[k]], ptx[k] * TILE_W, pty[k] * TILE_H, head.z, head.w);
+                const SetupRaster sr = s_rast[own[k]];
+                RasterRec rr;
+                rr.bx0 = sr.bx0; rr.bx1 = sr.bx1; rr.by0 = sr.by0; rr.by1 = sr.by1;
+                rr.x0 = sr.x0; rr.y0 = sr.y0; rr.x1 = sr.x1; rr.y1 = sr.y1; rr.x2 = sr.x2; rr.y2 = sr.y2;
+                pair_masks(rr, ptx[k] * TILE_W, pty[k] * TILE_H, a.cells != 0u, head.z, head.w);
                 dst[0] = head;
 #pragma unroll
                 for (int i = 1; i < P; i++) dst[i] = src[i];
@@ -197,24 +221,22 @@ __global__ __launch_bounds__(64) void k_setup_group(const SetupArgs *__restrict_
 }
 
 // -----------------------------------------------------------------------------------------
-// k_order_count, k_order_place
+// k_order
 // -----------------------------------------------------------------------------------------
-// Turn the per-tile polygon counts k_setup left into the tile kernel's work list: every tile once,
-// as (tile, count), bucketed by count -- >= 64, >= 32, ... , 1, and the empty tiles last.  With
-// the list the tile kernel needs one scalar load to know its tile and size (it used to chase list
-// length -> list entry -> counter), is launched with exactly one workgroup per tile, and packs by
-// eight weight classes (longest-processing-time first).
-// Two small kernels, one thread per tile: the first counts the buckets, the second gives every
-// tile its position.  A wave counts its members of a bucket with a ballot and issues one atomic
-// per bucket.  (A single workgroup doing both sweeps took 16-40 us: it shares one compute unit
-// with six resident waves per SIMD of the previous pass's tile kernel.)  Both run on the setup
-// stream beside that tile kernel.  The 16 words they use follow the tile counters (words
-// n_tiles .. n_tiles + 15: bucket sizes, then cursors) and rotate and get zeroed with them.
-// Inside a bucket the tiles come in a hashed order: consecutive workgroups are dealt round-robin
-// to the XCDs and their compute units, and tiles that are neighbours on the screen cost about the
-// same and read the same texture region -- in row-major order the tile kernel was 15 % slower.
+// Turns the per-tile polygon counts k_setup left into the tile kernel's WORK LISTS: every tile once, as
+// (tile, count), in one of eight lists by count -- >= 64, >= 32, ... , 1, and the empty tiles -- each with a
+// region of its own (n_tiles entries), so that ONE sweep suffices: a wave counts its members of a list with a
+// ballot, one lane per list reserves the wave's range with a single atomic, members take base + rank.  (Round 2
+// needed a counting sweep first, to know where each list starts in a common array: two dependent kernels in
+// front of every tile kernel.)  The tile kernel walks the lists heaviest first (longest-processing-time-first
+// packing) and handles the empty tiles in batches.  Inside a list the tiles come in a hashed order: tiles that
+// are neighbours on the screen cost about the same and read the same texture region -- in row-major order the
+// tile kernel was 15 % slower.  The kernel also zeroes the counters it has read (for the pass that uses the set
+// next); the 16 words behind them -- the list lengths -- are zeroed by k_setup's
+// first workgroup earlier in the same stream.
 constexpr int ORDER_BUCKETS = 8;
 constexpr int ORDER_THREADS = 256;
+constexpr int ORDER_EMPTY = ORDER_BUCKETS - 1;  // the list of the tiles without polygons
 
 // Bijection on [0, n): odd multiplications and xor-shifts are bijections on [0, 2^bits); values
 // that fall outside [0, n) are walked through the same map again (cycle walking).
@@ -233,46 +255,29 @@ __device__ __forceinline__ uint32_t scatter_tile(uint32_t b, uint32_t n, uint32_
 
 __device__ __forceinline__ uint32_t order_bucket(uint32_t n)
 {
-    if (n == 0u) return ORDER_BUCKETS - 1;
+    if (n == 0u) return ORDER_EMPTY;
     const uint32_t lg = 31u - (uint32_t)__builtin_clz(n);  // floor(log2 n)
     return lg >= (uint32_t)(ORDER_BUCKETS - 2) ? 0u : (uint32_t)(ORDER_BUCKETS - 2) - lg;
 }
 
-// `group` != null: blockIdx.y = frame of a group, whose counters and work list are in entry y of the tile
-// kernel's argument table (TileArgs::tile_count_next is the frame's own counter set there).
-__global__ __launch_bounds__(ORDER_THREADS) void k_order_count(uint32_t *tile_count, uint32_t n_tiles, uint32_t bits,
-                                                                const TileArgs *__restrict__ group)
+// `group` != null: blockIdx.y = frame of a group, whose counters and work lists are in entry y of the tile
+// kernel's argument table.
+__global__ __launch_bounds__(ORDER_THREADS) void k_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles,
+                                                          uint32_t bits, const TileArgs *__restrict__ group)
 {
-    if (group) tile_count = group[blockIdx.y].tile_count_next;
-    const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
-    const bool live = i < n_tiles;
-    const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
-    const uint32_t bk = order_bucket(live ? tile_count[t] : 0u);
-    // lane b ends up with the wave's size of bucket b; the eight lanes add in one instruction
-    uint32_t mine = 0u;
-#pragma unroll
-    for (int b = 0; b < ORDER_BUCKETS; b++) {
-        const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(live && bk == (uint32_t)b));
-        if (lane == (uint32_t)b) mine = c;
-    }
-    if (lane < (uint32_t)ORDER_BUCKETS && mine) atomicAdd(&tile_count[n_tiles + lane], mine);
-}
-
-__global__ __launch_bounds__(ORDER_THREADS) void k_order_place(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles,
-                                                                uint32_t bits, const TileArgs *__restrict__ group)
-{
+    uint32_t *lengths = tile_count + n_tiles;
     if (group) {
-        tile_count = group[blockIdx.y].tile_count_next;
+        tile_count = group[blockIdx.y].tile_count;
         order = const_cast<WorkItem *>(group[blockIdx.y].order);
+        lengths = const_cast<uint32_t *>(group[blockIdx.y].list_len);  // (zeroed by the host with the table)
     }
     const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const bool live = i < n_tiles;
     const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
     const uint32_t n = live ? tile_count[t] : 0u;
+    if (live && n != 0u) tile_count[t] = 0u;
     const uint32_t bk = order_bucket(n);
-    // lane b reserves the wave's range in bucket b (one atomic instruction, one round trip for all
-    // eight) and knows where the bucket starts; members then take base + rank
     uint32_t mine = 0u, rank = 0u;
 #pragma unroll
     for (int b = 0; b < ORDER_BUCKETS; b++) {
@@ -281,17 +286,13 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_place(uint32_t *tile_co
         if (bk == (uint32_t)b) rank = (uint32_t)__builtin_popcountll(m & below);
     }
     uint32_t base = 0u;
-    if (lane < (uint32_t)ORDER_BUCKETS) {
-        const uint32_t *sizes = tile_count + n_tiles;
-        for (uint32_t b = 0; b < lane; b++) base += sizes[b];
-        if (mine) base += atomicAdd(&tile_count[n_tiles + ORDER_BUCKETS + lane], mine);
-    }
+    if (lane < (uint32_t)ORDER_BUCKETS && mine) base = atomicAdd(&lengths[lane], mine);
     const uint32_t pos = (uint32_t)__shfl((int)base, (int)bk, 64) + rank;
     if (live) {
         WorkItem w;
         w.tile = t;
         w.count = n;
-        order[pos] = w;
+        order[(size_t)bk * n_tiles + pos] = w;
     }
 }
 
@@ -458,11 +459,6 @@ __device__ __forceinline__ uint32_t depth_order_bits(float z)
 template <int FS, int TILE_WAVES, bool SHARED, bool GROUP>
 TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ table, uint32_t n_frames)
 {
-    const uint32_t frame_of_group = GROUP ? blockIdx.x % n_frames : 0u;
-    const uint32_t work_index = GROUP ? blockIdx.x / n_frames : blockIdx.x;
-    // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
-    const TileArgs &a = GROUP ? *(const TileArgs *)((constant_ptr<TileArgs>)table + frame_of_group) : args;
-    uint64_t *const stamps = frame_of_group == 0u ? a.stamps : nullptr;  // the diagnostic stamps follow a group's first frame
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
     constexpr int QUAD_COLUMN = TILE_W / TILE_WAVES;  // width of a wave's column when columns are owned
@@ -483,26 +479,40 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     __shared__ uint32_t s_incl[SHARED ? TILE_THREADS : 1];
     __shared__ uint32_t s_wtot[SHARED ? TILE_WAVES : 1];
 
-    // One workgroup per tile, in the order k_order laid out: tiles with polygons first -- the long,
-    // VALU-bound ones, heaviest first (longest-processing-time-first packing, and the machine is
-    // full of them from the first microsecond) -- then the empty tiles, whose workgroups only
-    // stream the cleared colour of a fresh frame: short, HBM-bound work that fills the slots the
-    // busy tiles free.  Measured alternatives (profiles/r01_notes.md): interleaving the two kinds,
-    // or letting the busy blocks issue those stores themselves, was 5-10 % slower.  Any order is
-    // correct.  Every workgroup also zeroes its tile's counter for a later pass.
+    // One workgroup per tile and frame, in the order of the work lists (k_order): blockIdx = b * n_frames + f is
+    // entry b of frame f's lists walked heaviest first, so that the heavy tiles of ALL frames of a group are
+    // dispatched first -- the long, VALU-bound ones (longest-processing-time-first packing by the hardware's
+    // own dispatcher, and the machine is full of them from the first microsecond) -- then the light ones and
+    // the empty tiles, whose workgroups only check flags or stream the cleared colour of a fresh frame: short
+    // work that fills the slots the busy tiles free.  Measured alternatives: interleaving the two kinds, or
+    // letting the busy blocks issue those stores themselves, was 5-10 % slower (profiles/r01_notes.md); fewer
+    // workgroups that each take several tiles (a loop around this body) cost registers -- 7-13 spilled
+    // vector registers in the light closures' kernels -- and 4-12 % (profiles/r03_notes.md).  Any order is correct.
     const uint32_t tid = threadIdx.x;
-    const WorkItem work = a.order[work_index];
+    const uint32_t n_fr = GROUP ? n_frames : 1u;
+    const uint32_t frame_of_group = blockIdx.x % n_fr;
+    // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
+    const TileArgs &a = GROUP ? *(const TileArgs *)((constant_ptr<TileArgs>)table + frame_of_group) : args;
+    const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
+    uint32_t entry = blockIdx.x / n_fr;
+    uint32_t list = 0u;
+    {
+        // which list, which entry: a fused launch has the eight lengths in its table entry, a per-frame launch
+        // behind the pass's counters (one more scalar load)
+        constant_ptr<uint32_t> lengths = GROUP ? (constant_ptr<uint32_t>)a.list_len : (constant_ptr<uint32_t>)a.tile_count + n_tiles;
+#pragma unroll
+        for (int b = 0; b < ORDER_BUCKETS - 1; b++) {
+            const uint32_t len = lengths[b];
+            if (list == (uint32_t)b && entry >= len) {
+                entry -= len;
+                list = (uint32_t)b + 1u;
+            }
+        }
+    }
+    uint64_t *const stamps = frame_of_group == 0u ? a.stamps : nullptr;  // the diagnostic stamps follow a group's first frame
+    const WorkItem work = a.order[(size_t)list * n_tiles + entry];
     const uint32_t tile = work.tile;
     uint32_t n = work.count;
-    if (tid == 0u) a.tile_count_next[tile] = 0u;
-    if (work_index == 0u && tid < 2u * (uint32_t)ORDER_BUCKETS)
-        a.tile_count_next[a.frame.ntx * a.frame.nty + tid] = 0u;  // k_order's bucket sizes and cursors
-    if ((TR_DBG_SKIP & 8) && n == 0u) return;
-    if (TR_DBG_SKIP & 16) return;                       // every workgroup: dispatch + one load
-    if ((TR_DBG_SKIP & 32) && n != 0u) {                // busy tiles: stores only
-        write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W, (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, true);
-        return;
-    }
     if (n == 0u) {
         if (a.fresh) {
             // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
@@ -627,7 +637,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 const uint32_t items = small ? (uint32_t)(__popc(r0.z) + __popc(r0.w)) : 0u;
                 // block columns of this wave's region (bit i = column pair i: block rows 0 / 1) with a live
                 // block: what a visit iterates over
-                uint32_t lmask = (some && !small) ? pair_block_columns(r0.z, r0.w, pb, tile_x0) : 0u;
+                uint32_t lmask = (some && !small) ? pair_block_columns(r0.z, r0.w, SHARED && SCAN_ITEMS, pb, tile_x0) : 0u;
                 if (!SH) lmask = (lmask >> (NBX * wave)) & ((1u << NBX) - 1u);
                 // The polygon's part of to_barycentric_coord (scene.rs:178-187), for the 64 records
                 // of this round at once (lane l = record l).  Orientation is normalised so that
@@ -1315,20 +1325,25 @@ int rec_pieces_for_fs(int fs) { return fs == FS_DARBOUX ? REC_PIECES_LARGE : REC
 int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start,
                  hipEvent_t done)
 {
-    if (a.mesh.n_tri == 0) return 0;
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
-    // polygons per wave: all 64 lanes when that still gives the machine a few thousand waves (the x64 grid's
-    // 321 408 polygons), fewer for small meshes (8: 5 022 polygons = 628 waves per frame)
+    // polygons per wave: all 64 lanes when that still gives the machine a few hundred waves (the x64 grid's 321 408
+    // polygons; 32 for a group of four frames of 5 022), fewer for a lone frame of a small mesh, which waits for the
+    // slowest wave (8: 628 waves); never more than the LDS budget holds
     uint32_t polys = SETUP_POLYS;
-    while (polys > 8u && (uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 2048u) polys >>= 1;
-    const dim3 grid((a.mesh.n_tri + polys - 1u) / polys, group ? n_frames : 1u), block(64);
+    while (polys > 8u && ((uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 512u ||
+                          setup_lds_bytes(polys, a.rec_pieces) > SETUP_LDS_BUDGET))
+        polys >>= 1;
+    static const int forced = getenv("TR_SETUP_POLYS") ? atoi(getenv("TR_SETUP_POLYS")) : 0;  // experiment hook
+    if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && setup_lds_bytes((uint32_t)forced, a.rec_pieces) <= 16384u) polys = (uint32_t)forced;
+    const uint32_t lds = setup_lds_bytes(polys, a.rec_pieces);
+    const dim3 grid(a.mesh.n_tri ? (a.mesh.n_tri + polys - 1u) / polys : 1u, group ? n_frames : 1u), block(64);  // (an empty mesh: its first workgroup still zeroes the pass's list words)
 #define TR_SETUP_CASE(V)                                                                              \
     case V:                                                                                           \
         if (group)                                                                                    \
-            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group, polys);       \
+            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, lds, st, start, done, 0, group, polys);       \
         else                                                                                          \
-            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a, polys);                 \
+            hipExtLaunchKernelGGL(k_setup<V>, grid, block, lds, st, start, done, 0, a, polys);                 \
         break;
     switch (vs) {
     TR_SETUP_CASE(VS_DEFAULT)
@@ -1351,9 +1366,7 @@ int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, const 
     const dim3 grid((n_tiles + ORDER_THREADS - 1u) / ORDER_THREADS, group ? n_frames : 1u), block(ORDER_THREADS);
     uint32_t bits = 1;
     while ((1u << bits) < n_tiles) bits++;
-    hipExtLaunchKernelGGL(k_order_count, grid, block, 0, st, start, nullptr, 0, tile_count, n_tiles, bits, group);
-    TR_LAUNCH_CHECK();
-    hipExtLaunchKernelGGL(k_order_place, grid, block, 0, st, nullptr, done, 0, tile_count, order, n_tiles, bits, group);
+    hipExtLaunchKernelGGL(k_order, grid, block, 0, st, start, done, 0, tile_count, order, n_tiles, bits, group);
     TR_LAUNCH_CHECK();
     return 0;
 }

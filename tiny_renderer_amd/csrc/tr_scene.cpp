@@ -112,6 +112,7 @@ constexpr int SETS = LOOKAHEAD + 1;
 // gives 34.2 (same box), and at small frames 25 -> 20.5 us (800^2), 24.8 -> 22.4 (2048^2).
 constexpr int BATCH = LOOKAHEAD - 1;  // passes that may be pending (setup queued, tile kernel not yet)
 constexpr int RING = 16;  // events: pass p's are waited for until pass p + LOOKAHEAD is set up
+constexpr size_t ORDER_LISTS = 8;  // k_order's work lists per pass, n_tiles entries each (tr_kernels.hip)
 
 // Frame groups (tr_scene_render_frames).  A lone frame cannot keep the GPU full: at 4096^2 a third of the tile
 // kernel runs on a machine that is draining (2 168 busy tiles on 1 536 workgroup slots), and smaller frames never
@@ -215,6 +216,7 @@ struct tr_scene {
         bool in_flight = false;
         uint32_t bin_cap = 0, frames = 0;  // what the set was allocated for
         uint32_t g = 0;                    // frames of the group it holds now
+        int tile_waves[2] = { 4, 4 }, shared[2] = { 0, 0 };  // the tile kernels' layout, per pass (decided with the setup)
         bool chain_on_main = false;        // its setup was queued on the main stream itself (nothing was in flight)
     } grp[GROUP_SETS];
     uint64_t group_seq = 0;       // groups whose setup has been queued
@@ -603,6 +605,7 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     uint32_t need = 0;
     HIP_TRY(hipMemcpy(&need, s->d_bin_need, sizeof need, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_bin_need, 0, sizeof need));
+    HIP_TRY(hipStreamSynchronize(nullptr));  // (the scene's streams do not wait for the null stream)
     uint64_t cap = s->bin_cap;
     while (cap < need) cap *= 2;
     if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
@@ -623,10 +626,14 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     }
     if (st != TR_OK) return st;
     // (the frame groups' bins follow bin_cap when their set is next used)
-    if (first_bad_seq < s->observed_seq)
-        return tr::fail(TR_E_BIN_OVERFLOW,
-                        "triangle bins overflowed in a frame that was already handed on (asynchronous read-back or "
-                        "caller's stream): that frame is truncated; the bins have been grown: render it again");
+    if (first_bad_seq < s->observed_seq) {
+        char buf[320];
+        snprintf(buf, sizeof buf,
+                 "triangle bins overflowed in a frame that was already handed on (asynchronous read-back or caller's "
+                 "stream): that frame is truncated; the bins have been grown to %u records per tile (a tile asked for %u, "
+                 "pass %llu of %llu): render it again", s->bin_cap, need, first_bad_seq, (unsigned long long)s->pass_seq);
+        return tr::fail(TR_E_BIN_OVERFLOW, buf);
+    }
     if (s->last_was_group) return replay_tail(s);  // frames older than the tail no longer exist anywhere
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
@@ -654,10 +661,14 @@ int take_device_errors(tr_scene *s, uint32_t &err, unsigned long long &first_bad
     err = 0;
     first_bad_seq = ~0ull;
     HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
-    if (err) HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
+    if (err) {
+        HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
+        HIP_TRY(hipStreamSynchronize(nullptr));         // (the scene's streams do not wait for the null stream)
+    }
     if (err & DE_BIN_OVERFLOW) {
         HIP_TRY(hipMemcpy(&first_bad_seq, s->d_overflow_seq, sizeof first_bad_seq, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(s->d_overflow_seq, 0xFF, sizeof first_bad_seq));
+        HIP_TRY(hipStreamSynchronize(nullptr));
     }
     return TR_OK;
 }
@@ -750,6 +761,9 @@ void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, uint32_t tiles_per
     // 50.4 -> 47.6, x4 (2.5) 38.9 -> 38.5, one model (0.6) 33.5 -> 35.4
     const bool dense = (uint64_t)s->mesh.n_tri >= 3ull * (tiles_per_frame ? tiles_per_frame : 1u);
     shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto((tiles_per_frame <= 2048u || dense) ? 1 : 0);
+    // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns.  Decided
+    // HERE, once per pass: k_setup prepares the pairs' masks for the form the tile kernel will run (SetupArgs::cells)
+    if (s->mesh.n_tri > (1u << 20) || s->bin_cap > 4093u) shared = 0;
 }
 
 int run_pass(tr_scene *s, const PassDesc &p)
@@ -781,12 +795,17 @@ int run_pass(tr_scene *s, const PassDesc &p)
 
     const DevFrame &frame = depth_pass ? s->frame_full : s->frame;
 
+    const uint32_t n_tiles_pass = frame.ntx * frame.nty;
+    tr_scene::PendingTile pt;
+    tile_layout(s, n_tiles_pass, n_tiles_pass, pt.tile_waves, pt.shared);
+
     SetupArgs sa;
     sa.mesh = s->mesh;
     sa.frame = frame;
     sa.u = du;
+    sa.cells = pt.shared ? 1u : 0u;
     tr_scene::BinState &bs = depth_pass ? s->bin_depth : s->bin_color;
-    const int set_cur = (int)(bs.seq % SETS), set_zero = (int)((bs.seq + SETS - 1) % SETS);
+    const int set_cur = (int)(bs.seq % SETS);
     const uint64_t p_seq = s->pass_seq;
     Piece *bins = s->d_bins[p_seq % LOOKAHEAD];
     sa.tile_count = bs.count[set_cur];
@@ -808,7 +827,6 @@ int run_pass(tr_scene *s, const PassDesc &p)
     hipStream_t chain = chain_on_main ? s->stream : s->setup_stream;
     if (!chain_on_main && p_seq >= (uint64_t)LOOKAHEAD)
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
-    const uint32_t n_tiles_pass = frame.ntx * frame.nty;
     if (!s->profiling) {
         int rc = launch_setup(p.vs, sa, nullptr, 0, chain, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
@@ -832,7 +850,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.bin_cap = s->bin_cap;
     ta.rec_pieces = s->rec_pieces;
     ta.order = s->d_order[p_seq % LOOKAHEAD];
-    ta.tile_count_next = bs.count[set_zero];
+    ta.tile_count = bs.count[set_cur];
     ta.frame = frame;
     ta.u = du;
     ta.tex = s->tex;
@@ -848,9 +866,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
-    tr_scene::PendingTile pt;
     pt.fs = p.fs;
-    tile_layout(s, n_tiles_pass, n_tiles_pass, pt.tile_waves, pt.shared);
     pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
     pt.p_seq = p_seq;
     pt.args = ta;
@@ -976,8 +992,13 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
         gs.frames = 0;
         const size_t nc = np * frames * group_counts_per_frame(s);
         if ((st = dev_alloc(&gs.count, nc))) return st;
-        HIP_TRY(hipMemset(gs.count, 0, nc * 4));  // from here on every tile kernel zeroes its own frame's counters
-        if ((st = dev_alloc(&gs.order, np * frames * (size_t)s->n_tiles_full))) return st;
+        // (from here on k_order zeroes the counters it has read.)  hipMemset returns before the device has
+        // executed it and the scene's streams do not wait for the null stream: without the synchronisation the
+        // set's first k_setup could count on top of whatever the fresh allocation held (an intermittent "bin
+        // overflow" the first time a fourth group was in flight)
+        HIP_TRY(hipMemset(gs.count, 0, nc * 4));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if ((st = dev_alloc(&gs.order, np * frames * (size_t)s->n_tiles_full * ORDER_LISTS))) return st;
         const size_t tb = np * frames * (sizeof(SetupArgs) + sizeof(TileArgs));
         if ((st = dev_alloc(&gs.d_tables, tb))) return st;
         HIP_TRY(hipHostMalloc((void **)&gs.h_tables, tb, hipHostMallocDefault));
@@ -1026,6 +1047,10 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
     const SetupArgs *d_setup = reinterpret_cast<const SetupArgs *>(gs.d_tables);
     const TileArgs *d_tile = reinterpret_cast<const TileArgs *>(gs.d_tables + (size_t)np * G * sizeof(SetupArgs));
 
+    for (uint32_t pi = 0; pi < np; pi++) {
+        const DevFrame &fr = pd.pass[pi].fs == FS_DEPTH ? s->frame_full : s->frame;
+        tile_layout(s, (uint64_t)fr.ntx * fr.nty * g, fr.ntx * fr.nty, gs.tile_waves[pi], gs.shared[pi]);
+    }
     float keep[12];
     memcpy(keep, s->light, 12); memcpy(keep + 3, s->from, 12); memcpy(keep + 6, s->at, 12); memcpy(keep + 9, s->up, 12);
     for (uint32_t j = 0; j < g && st == TR_OK; j++) {
@@ -1057,11 +1082,12 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             sa.err = s->d_err;
             sa.overflow_seq = s->d_overflow_seq;
             sa.pass_seq = s->pass_seq + (uint64_t)j * np + pi;  // frame by frame, as the per-frame path numbers them
+            sa.cells = gs.shared[pi] ? 1u : 0u;
             ta.bins = sa.bins;
             ta.bin_cap = s->bin_cap;
             ta.rec_pieces = s->rec_pieces;
-            ta.order = gs.order + e * (size_t)s->n_tiles_full;
-            ta.tile_count_next = sa.tile_count;  // dead once the work list exists: the tile kernel zeroes them for the set's next group
+            ta.order = gs.order + e * (size_t)s->n_tiles_full * ORDER_LISTS;
+            ta.tile_count = sa.tile_count;
             ta.frame = frame;
             ta.u = sa.u;
             ta.tex = s->tex;
@@ -1129,8 +1155,7 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
     for (uint32_t pi = 0; pi < np; pi++) {
         const PassDesc &pass = pd.pass[pi];
         const TileArgs &ta0 = h_tile[(size_t)pi * G];
-        int tile_waves = 4, shared = 0;
-        tile_layout(s, (uint64_t)ta0.frame.ntx * ta0.frame.nty * g, ta0.frame.ntx * ta0.frame.nty, tile_waves, shared);
+        const int tile_waves = gs.tile_waves[pi], shared = gs.shared[pi];
         EventPair ep = { nullptr, nullptr, pass.fs == FS_DEPTH ? K_TILE_DEPTH : K_TILE, g };
         if (s->profiling) {
             ep.a = take_event(s);
@@ -1529,7 +1554,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         }
     }
     for (int k = 0; k < LOOKAHEAD; k++)
-        if ((st = dev_alloc(&s->d_order[k], (size_t)s->n_tiles_full))) return st;
+        if ((st = dev_alloc(&s->d_order[k], (size_t)s->n_tiles_full * ORDER_LISTS))) return st;
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
     uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
     if (cap > mesh->n_tri) cap = mesh->n_tri;               // a bin never holds more than all polygons

@@ -230,8 +230,8 @@ TR_HD bool covers_oriented(float cx, float cy, float cz_positive)
 //   SMALL pair (box inside the tile at most SCAN_MAX_CHUNKS 8-pixel chunks wide, counted from the even
 //   pixel at or left of its first column): 64 cells, bit 4 * row + chunk, row 0 = the box's first row
 //   inside the tile, chunk c = pixels xs + 8c .. xs + 8c + 7 of that row.
-//   LARGE pair: bits 0..15 of `lo` = the 8-pixel wide block columns of the tile (both block rows) with a
-//   live 8x8 block.
+//   LARGE pair -- and every pair of a pass whose tile kernel owns columns (cells = false) -- : bits 0..15 of
+//   `lo` = the 8-pixel wide block columns of the tile (both block rows) with a live 8x8 block.
 constexpr int SCAN_MAX_CHUNKS = 4;
 
 struct PairBox {
@@ -261,7 +261,7 @@ TR_HD float fma_est(float a, float b, float c)
 #endif
 }
 
-TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, uint32_t &lo, uint32_t &hi)
+TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool cells, uint32_t &lo, uint32_t &hi)
 {
     const PairBox pb = pair_box(r.bx0, r.bx1, r.by0, r.by1, tile_x0, tile_y0);
     lo = hi = 0u;
@@ -274,7 +274,7 @@ TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, uint
         a0 = -a0; a1 = -a1; b0 = -b0; b1 = -b1;
         cz = -cz;
     }
-    const bool small = pb.nch <= SCAN_MAX_CHUNKS;
+    const bool small = cells && pb.nch <= SCAN_MAX_CHUNKS;
     const int32_t org_x = small ? pb.xs : tile_x0, org_y = small ? pb.ay0 : tile_y0;
     const float ox = (float)isub(r.x0, org_x), oy = (float)isub(r.y0, org_y);
     const float e0x = b1, e0y = -a1, e1x = -b0, e1y = a0, e2x = b0 - b1, e2y = a1 - a0;
@@ -319,9 +319,9 @@ TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, uint
 // Block columns of the tile (8 pixels wide, bit i) that can hold a fragment of a pair, from its masks:
 // a large pair's `lo` as it is; a small pair's from the chunk columns of its cells (a chunk starts at an
 // even pixel and may straddle two block columns).
-TR_HD uint32_t pair_block_columns(uint32_t lo, uint32_t hi, const PairBox &pb, int32_t tile_x0)
+TR_HD uint32_t pair_block_columns(uint32_t lo, uint32_t hi, bool cells, const PairBox &pb, int32_t tile_x0)
 {
-    if (pb.nch > SCAN_MAX_CHUNKS) return lo & 0xFFFFu;
+    if (!cells || pb.nch > SCAN_MAX_CHUNKS) return lo & 0xFFFFu;
     uint32_t c = lo | hi;
     c |= c >> 16;
     c |= c >> 8;

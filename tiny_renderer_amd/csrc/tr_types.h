@@ -177,18 +177,24 @@ struct SetupArgs {
     // overflow bookkeeping: the smallest `pass_seq` of a pass that overflowed a bin (atomic minimum)
     unsigned long long *overflow_seq;
     unsigned long long pass_seq;
+    // 1: the tile kernel resolves small pairs as scan-line items (shared form): they get cell masks; 0: every pair
+    // gets the block columns (pair_masks, tr_shaders.h)
+    uint32_t cells;
 };
 
 struct TileArgs {
     const Piece *bins;
     uint32_t bin_cap;
     uint32_t rec_pieces;
-    // The launch's work list, one entry per tile (built by k_order from this pass's counters):
-    // workgroup b renders tile order[b].x, which holds order[b].y polygons; heaviest first, the
-    // empty tiles last.  Counters rotate between passes of the same kind: each workgroup zeroes its
-    // tile's counter in the set a later pass will fill.
+    // The pass's work lists (k_order, from this pass's counters): eight regions of n_tiles entries, region b =
+    // the tiles of weight class b as (tile, polygons in its bin), the last region the empty tiles.
     const WorkItem *order;
-    uint32_t *tile_count_next;
+    // This pass's counter set: n_tiles counters (k_order has zeroed them again), then 16 words, the first eight
+    // of which hold the lists' lengths of a per-frame launch.  A fused launch's lengths are in its table entry
+    // (list_len, zeroed by the host, filled by k_order): the tile kernel finds them with its other arguments
+    // instead of behind one more dependent load.
+    uint32_t *tile_count;
+    uint32_t list_len[8];
     DevFrame frame;
     DevUniforms u;
     DevTextures tex;
