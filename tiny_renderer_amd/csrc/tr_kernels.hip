@@ -122,7 +122,10 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, u
             cnt = ntx * (r.by1 / TILE_H - ty0 + 1);
         }
     }
-    if (err) atomicOr(a.err, err);
+    if (err) {
+        atomicOr(a.err, err);
+        *a.alarm = 1u;
+    }
 
     // Binning.  One lane per polygon would serialise a polygon's atomics (a polygon spanning 30
     // tiles = 30 dependent round trips); instead the wave's (polygon, tile) pairs are numbered by
@@ -193,6 +196,7 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, u
                 for (int i = 1; i < P; i++) dst[i] = src[i];
             } else {
                 atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
+                *a.alarm = 1u;
                 atomicMax(a.bin_need, slot[k] + 1u);
                 atomicMin(a.overflow_seq, a.pass_seq);
             }
@@ -1040,7 +1044,10 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             tri[1] = qb[3].y;
             err |= eb;
         }
-        if (err) atomicOr(a.err, err);
+        if (err) {
+            atomicOr(a.err, err);
+            *a.alarm = 1u;
+        }
         return redo;
     };
 

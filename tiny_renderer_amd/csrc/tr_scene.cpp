@@ -260,6 +260,9 @@ struct tr_scene {
     uint32_t *d_fbclean = nullptr;  // the current target's set
     uint64_t *d_stamps = nullptr;
     uint32_t *d_err = nullptr;
+    // page-locked host word the kernels set beside d_err (TileArgs::alarm), and its device address
+    volatile uint32_t *h_alarm = nullptr;
+    uint32_t *d_alarm = nullptr;
 
     // Lazy clear (scene.rs:128-137): `clear` only records that the targets are logically
     // f32::MIN / 0; the next render writes every pixel of them anyway, and a getter that comes
@@ -660,6 +663,8 @@ int take_device_errors(tr_scene *s, uint32_t &err, unsigned long long &first_bad
 {
     err = 0;
     first_bad_seq = ~0ull;
+    if (*s->h_alarm == 0u) return TR_OK;  // nothing was raised since the last look: no copy
+    *s->h_alarm = 0u;
     HIP_TRY(hipMemcpy(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
         HIP_TRY(hipMemset(s->d_err, 0, sizeof err));  // the word is per frame, not sticky
@@ -814,6 +819,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     sa.rec_pieces = s->rec_pieces;
     sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
+    sa.alarm = s->d_alarm;
     sa.overflow_seq = s->d_overflow_seq;
     sa.pass_seq = p_seq;
     // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p.
@@ -862,6 +868,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.fbclean = depth_pass ? nullptr : s->d_fbclean;
     ta.sclean = (p.fs == FS_SHADOW2 || p.fs == FS_OCCLUSION2) ? s->d_sclean : nullptr;
     ta.err = s->d_err;
+    ta.alarm = s->d_alarm;
     ta.fresh = fresh;
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
@@ -1080,6 +1087,7 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             sa.rec_pieces = s->rec_pieces;
             sa.bin_need = s->d_bin_need;
             sa.err = s->d_err;
+            sa.alarm = s->d_alarm;
             sa.overflow_seq = s->d_overflow_seq;
             sa.pass_seq = s->pass_seq + (uint64_t)j * np + pi;  // frame by frame, as the per-frame path numbers them
             sa.cells = gs.shared[pi] ? 1u : 0u;
@@ -1099,6 +1107,7 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             ta.fbclean = depth_pass ? nullptr : fbclean;
             ta.sclean = (pass.fs == FS_SHADOW2 || pass.fs == FS_OCCLUSION2) ? slot.sclean : nullptr;
             ta.err = s->d_err;
+            ta.alarm = s->d_alarm;
             ta.fresh = 1u;  // every frame of a group starts from cleared targets
             ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
             ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
@@ -1442,6 +1451,7 @@ void destroy(tr_scene *s)
     for (tr_scene::FbFlags &f : s->fb_flags) dev_free(f.clean);
     dev_free(s->d_stamps);
     dev_free(s->d_err);
+    if (s->h_alarm) (void)hipHostFree((void *)s->h_alarm);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1598,6 +1608,14 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     }
     if ((st = dev_alloc(&s->d_err, 1))) return st;
     HIP_TRY(hipMemset(s->d_err, 0, 4));
+    {
+        void *h = nullptr, *d = nullptr;
+        HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+        s->h_alarm = (volatile uint32_t *)h;
+        s->d_alarm = (uint32_t *)d;
+        *s->h_alarm = 0u;
+    }
     HIP_TRY(hipDeviceSynchronize());
     return TR_OK;
 }

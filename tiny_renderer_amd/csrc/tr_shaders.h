@@ -284,21 +284,27 @@ TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool
                          (((fabsf(a1) + fabsf(a0)) * (fabsf(oy) + (float)TILE_H) +
                            (fabsf(b1) + fabsf(b0)) * (fabsf(ox) + (small ? 8.0f * SCAN_MAX_CHUNKS : (float)TILE_W))) + cz);
     const float px0 = fmaxf(e0x, 0.0f), px1 = fmaxf(e1x, 0.0f), px2 = fmaxf(e2x, 0.0f);
+    // (the loops run over the box's own rows / block columns only: on the device they stay rolled -- eight copies of
+    // a fully unrolled form in k_setup's pair loop were 45 KB of code and most of that kernel's time)
     if (small) {
         const float m0 = e0 + (7.0f * px0 + margin), m1 = e1 + (7.0f * px1 + margin), m2 = e2 + (7.0f * px2 + 2.0f * margin);
         const int32_t rows = pb.ay1 - pb.ay0 + 1;
-        for (int j = 0; j < TILE_H; j++) {
+        const uint32_t in_box = (1u << pb.nch) - 1u;
+        unsigned long long cells_mask = 0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int j = 0; j < rows; j++) {
             const float n0 = fma_est((float)j, e0y, m0), n1 = fma_est((float)j, e1y, m1), n2 = fma_est((float)j, e2y, m2);
             uint32_t bits = 0u;
             for (int c = 0; c < SCAN_MAX_CHUNKS; c++) {
                 const float worst = fminf(fminf(fma_est(8.0f * c, e0x, n0), fma_est(8.0f * c, e1x, n1)), fma_est(8.0f * c, e2x, n2));
-                bits |= (worst >= 0.0f && c < pb.nch && j < rows) ? 1u << c : 0u;
+                bits |= worst >= 0.0f ? 1u << c : 0u;
             }
-            if (j < 8)
-                lo |= bits << (4 * j);
-            else
-                hi |= bits << (4 * (j - 8));
+            cells_mask |= (unsigned long long)(bits & in_box) << (4 * j);
         }
+        lo = (uint32_t)cells_mask;
+        hi = (uint32_t)(cells_mask >> 32);
     } else {
         const float py0 = fmaxf(e0y, 0.0f), py1 = fmaxf(e1y, 0.0f), py2 = fmaxf(e2y, 0.0f);
         const float m0 = e0 + (7.0f * (px0 + py0) + margin), m1 = e1 + (7.0f * (px1 + py1) + margin);
@@ -306,11 +312,18 @@ TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool
         // block columns / rows the box meets
         const int32_t ia = isub(pb.ax0, tile_x0) >> 3, ib = isub(pb.ax1, tile_x0) >> 3;
         const int32_t ja = isub(pb.ay0, tile_y0) >> 3, jb = isub(pb.ay1, tile_y0) >> 3;
-        for (int j = 0; j < TILE_H / 8; j++) {
-            const float n0 = fma_est(8.0f * j, e0y, m0), n1 = fma_est(8.0f * j, e1y, m1), n2 = fma_est(8.0f * j, e2y, m2);
-            for (int i = 0; i < TILE_W / 8; i++) {
-                const float worst = fminf(fminf(fma_est(8.0f * i, e0x, n0), fma_est(8.0f * i, e1x, n1)), fma_est(8.0f * i, e2x, n2));
-                lo |= (worst >= 0.0f && i >= ia && i <= ib && j >= ja && j <= jb) ? 1u << i : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int j = ja; j <= jb; j++) {
+            const float n0 = fma_est(8.0f * (float)j, e0y, m0), n1 = fma_est(8.0f * (float)j, e1y, m1), n2 = fma_est(8.0f * (float)j, e2y, m2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 2
+#endif
+            for (int i = ia; i <= ib; i++) {
+                const float x = 8.0f * (float)i;
+                const float worst = fminf(fminf(fma_est(x, e0x, n0), fma_est(x, e1x, n1)), fma_est(x, e2x, n2));
+                lo |= worst >= 0.0f ? 1u << i : 0u;
             }
         }
     }

@@ -174,6 +174,7 @@ struct SetupArgs {
     uint32_t rec_pieces;
     uint32_t *bin_need;
     uint32_t *err;
+    uint32_t *alarm;    // page-locked host word (mapped): set to 1 with whatever is raised in `err` (see TileArgs)
     // overflow bookkeeping: the smallest `pass_seq` of a pass that overflowed a bin (atomic minimum)
     unsigned long long *overflow_seq;
     unsigned long long pass_seq;
@@ -203,6 +204,10 @@ struct TileArgs {
     uint8_t *fb;        // 3*W*H, row 0 = top (already flipped: scene.rs:92-97 folded in)
     uint32_t *winner;   // W*H or nullptr
     uint32_t *err;
+    // A word in page-locked HOST memory, set (plain store) whenever a bit is raised in `err`: the host looks at it
+    // after waiting for the stream and copies the device words only when it is up -- a frame without errors costs
+    // no device-to-host copy at its sync (10 us of the 13 an empty tr_scene_sync took).
+    uint32_t *alarm;
     uint32_t fresh;     // 1: target buffers are logically cleared (scene.rs:128-137 folded in)
     uint32_t aligned16; // 1: width % 16 == 0, cleared rows can be written in 16-byte pieces
     uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
