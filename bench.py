@@ -225,7 +225,8 @@ def main():
     scene = T.Scene(W, H, mesh, texs, pipe, device=device_index,
                     stream=render_stream.cuda_stream if use_dist else None,
                     frame_buffer_device=fb_ptr[0] if use_dist else None, band_rows=band,
-                    frames_per_launch=args.frames_per_launch)
+                    frames_per_launch=args.frames_per_launch,
+                    trust_frame_buffers=use_dist)   # (the frame tensors are written by this scene and the exchange only)
     frames_per_launch = scene.frames_per_launch if grouped else 1
     chunks = None
     band_bytes = 0

@@ -64,6 +64,14 @@ typedef struct tr_image_rgb8 {
 #define TR_OPT_WINNER_TAP 0x1u /* keep a per-pixel winning-polygon index (parity tap) */
 #define TR_OPT_TILE_STAMPS 0x2u /* diagnostic: record per-tile start/end clocks of the last pass */
 #define TR_OPT_NO_AUTO_GROUP 0x4u /* tr_scene_render submits every frame on its own (see tr_scene_render) */
+/* A caller's frame buffers (tr_options.frame_buffer_device, tr_scene_set_frame_buffer_device, tr_scene_render_frames)
+ * are written by nobody but the scene while they are its targets -- apart from rows outside the scene's band.  The
+ * scene then keeps, per buffer, which tiles already hold the cleared colour, and a cleared frame does not store the
+ * zeros of an empty tile again (a caller that double-buffers frames for an exchange: most of the frame, every frame).
+ * Without the flag nothing is remembered about a caller's buffer from one tr_scene_set_frame_buffer_device /
+ * tr_scene_render_frames call to the next: whatever wrote it in between -- a post-process, a memset, an allocator
+ * handing the address to another tensor -- a cleared render produces every pixel of its band. */
+#define TR_OPT_TRUST_FRAME_BUFFERS 0x8u
 
 typedef struct tr_options {
     uint32_t struct_size;      /* = sizeof(tr_options) */
@@ -226,6 +234,17 @@ int tr_scene_profile_frame_intervals(tr_scene *s, float *out_us, int cap);
  * outputs are host arrays of n elements; div_ref receives the device's plain x / d. */
 int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t n, uint32_t *out_u32,
                             int32_t *out_i32, uint32_t *out_u8, float *out_div, float *out_div_ref);
+
+/* Device self-test of the shadow-buffer lookup of the shadow / occlusion closures (shader.rs:774-778, 909-912,
+ * 932-935: (round(x) as u32 + round(y) as u32 * width) as usize, wrapping) as the kernels perform it THROUGH the
+ * shadow buffer's per-tile fast-clear flags: `stale` is a width x height buffer whose tiles with a non-zero flag in
+ * `sclean` (one word per 128 x 16 tile, row-major) hold arbitrary values, `plain` the same buffer with those tiles
+ * written as f32::MIN.  For each of the n coordinates the value bits and error bits (4 = index out of range) of the
+ * plain lookup in `plain` and of the flagged lookup in `stale` are returned; they must be equal -- also for a
+ * column beyond the row and for a row k * 2^32 / width + r, which wraps around 2^32 back into the buffer. */
+int tr_selftest_shadow_fetch(int device, uint32_t width, uint32_t height, const float *plain, const float *stale,
+                             const uint32_t *sclean, uint32_t n, const float *x, const float *y, uint32_t *out_plain,
+                             uint32_t *out_flagged, uint32_t *err_plain, uint32_t *err_flagged);
 
 /* Exhaustive device check of the kernels' own correctly rounded reciprocal (which = 0) and square
  * root (which = 1) for pixel pairs (csrc/tr_pk.h rcp2 / sqrt2: hardware estimate + fused residual

@@ -379,6 +379,43 @@ def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
     assert_parity(gpu, cpu, pipe)
 
 
+def test_shadow_fetch_through_flags_on_the_device(built):
+    """The DEVICE's shadow_fetch through the shadow buffer's fast-clear flags (the form that once took the flag's
+    tile from (x, y) and faulted: a row k * 2^32 / W + r wraps, as upstream, to a valid flat index) against the
+    plain lookup in the materialised buffer: coordinates inside the frame, columns beyond the row, rows that wrap
+    around 2^32 back into the buffer, out of range, negative, NaN (shader.rs:774-778, 909-912, 932-935)."""
+    import tiny_renderer_amd as T
+    from tests import emul_bind as E
+    L = T.load_library()
+    rng = np.random.default_rng(11)
+    for W, Hh in ((512, 512), (640, 100), (130, 70), (4096, 64)):
+        ntx, nty = (W + 127) // 128, (Hh + 15) // 16
+        plain = rng.standard_normal(W * Hh).astype(np.float32)
+        flags = (rng.random(ntx * nty) < 0.5).astype(np.uint32) * np.uint32(0xFFFFFFFF)
+        tile_of = (np.arange(Hh)[:, None] // 16) * ntx + (np.arange(W)[None, :] // 128)
+        clean = flags[tile_of].astype(bool).reshape(-1)
+        plain[clean] = np.float32(np.finfo(np.float32).min)
+        stale = plain.copy()
+        stale[clean] = np.float32(123.0)
+        xs = [rng.uniform(-3, W + 3, 4000), rng.uniform(W, 40 * W, 2000), rng.uniform(0, W, 3000), rng.uniform(0, W, 500)]
+        ys = [rng.uniform(-3, Hh + 3, 4000), rng.uniform(0, Hh / 2, 2000),
+              (rng.integers(1, 64, 3000) * (2.0 ** 32 / W)) + rng.integers(0, Hh, 3000),   # wraps around 2^32
+              rng.uniform(Hh, 1e9, 500)]
+        x = np.ascontiguousarray(np.concatenate(xs + [[np.nan, 0.0, -1e30, 1e30]]).astype(np.float32))
+        y = np.ascontiguousarray(np.concatenate(ys + [[0.0, np.nan, 5.0, 1e30]]).astype(np.float32))
+        n = len(x)
+        out = [np.zeros(n, np.uint32) for _ in range(4)]
+        T._lib.check(L.tr_selftest_shadow_fetch(0, W, Hh, plain.ctypes.data, stale.ctypes.data, flags.ctypes.data, n,
+                                                x.ctypes.data, y.ctypes.data, *[o.ctypes.data for o in out]))
+        assert np.array_equal(out[0], out[1]), (W, Hh, int((out[0] != out[1]).sum()))
+        assert np.array_equal(out[2], out[3])
+        assert (out[2] == 0).sum() > 5000 and (out[2] != 0).sum() > 100   # lookups inside the buffer, and flagged ones
+        assert (out[2][6000:9000] == 0).sum() > 100                        # the wrapped rows do land inside the buffer
+        # ... and the host's emulation of the same function agrees with itself on these inputs
+        assert E.lib().tr_emul_shadow_fetch_mismatches(plain.ctypes.data, stale.ctypes.data, flags.ctypes.data, W, Hh,
+                                                       x.ctypes.data, y.ctypes.data, n) == 0
+
+
 def test_device_math_selftest(built):
     """The instruction-level substitutions on the device: v_cvt_{u32,i32}_f32 as Rust `as` casts
     and the shared-reciprocal division against the device's own '/' and the host's."""
@@ -603,6 +640,99 @@ def test_caller_stream_consumes_frames_without_sync(small_synthetic):
         assert cpu.render() == 0
         assert np.array_equal(kept[f].cpu().numpy().reshape(Hh, W, 3), cpu.get_frame_buffer()), "frame %d" % f
     gpu.close()
+
+
+def test_a_callers_buffer_rewritten_behind_the_scenes_back(small_synthetic):
+    """Colour-clean flags of a CALLER's buffer are forgotten whenever the buffer is handed over again: a cleared
+    render then produces every pixel of the frame, whatever wrote the buffer in between (a post-process, a memset,
+    an allocator giving the address to another tensor).  With TR_OPT_TRUST_FRAME_BUFFERS the caller promises not
+    to, and the empty tiles' zeros are not stored a second time."""
+    import torch
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 640, 384
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    cpu.clear(), cpu.set_light_direction(H.light(0.2)), cpu.set_camera(*H.camera(0.3)), cpu.render()
+    want = cpu.get_frame_buffer()
+    assert (want == 0).all(-1).mean() > 0.3          # a good part of the frame is empty tiles
+    for trust in (False, True):
+        buf = torch.zeros(Hh * W * 3, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu = T.Scene(W, Hh, mesh, texs, "phong", frame_buffer_device=buf.data_ptr(), trust_frame_buffers=trust)
+        for rep in range(3):
+            gpu.set_frame_buffer_device(buf.data_ptr())
+            gpu.clear(), gpu.set_light_direction(H.light(0.2)), gpu.set_camera(*H.camera(0.3)), gpu.render()
+            assert gpu.sync() == 0
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy().reshape(Hh, W, 3)
+            if rep < 2 or not trust:
+                assert np.array_equal(got, want), "trust %s, render %d" % (trust, rep)
+            else:
+                # the promise was broken below: the scene did not store the empty tiles again (that is the saving)
+                assert (got == 77).any() and np.array_equal(got[want.any(-1)], want[want.any(-1)])
+            if rep == 1:
+                buf.fill_(77)                         # somebody else writes the buffer
+                torch.cuda.synchronize()
+        gpu.close()
+    cpu.close()
+
+
+def test_bin_overflow_in_an_older_frame_of_a_call_with_callers_buffers(synthetic):
+    """tr_scene_render_frames with more frames than a launch holds, every frame into a buffer of the caller's, bins
+    too small: the frames older than the last group cannot be rendered again, so the sync says TR_E_BIN_OVERFLOW
+    (never TR_OK with truncated frames in the caller's hands); rendered again with the grown bins, every buffer
+    holds its frame."""
+    import torch
+    import tiny_renderer_amd as T
+    mesh, texs = synthetic
+    W, Hh, n = 512, 384, 6
+    p = np.zeros((n, 12), np.float32)
+    for f in range(n):
+        p[f, 0:3] = H.light(0.1 * f)
+        p[f, 3:6], p[f, 6:9], p[f, 9:12] = H.camera(0.4 * f)
+    bufs = [torch.zeros(Hh * W * 3, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", bin_capacity=64, frames_per_launch=2)
+    gpu.render_frames(p, [b.data_ptr() for b in bufs])
+    with pytest.raises(T.TinyRendererError) as e:
+        gpu.sync()
+    assert e.value.code == -9
+    gpu.render_frames(p, [b.data_ptr() for b in bufs])
+    assert gpu.sync() == 0
+    torch.cuda.synchronize()
+    for f in range(n):
+        err, s = H_oracle(W, Hh, mesh, texs, "phong", p[f])
+        assert np.array_equal(bufs[f].cpu().numpy().reshape(Hh, W, 3), s), "frame %d" % f
+    gpu.close()
+
+
+def H_oracle(W, Hh, mesh, texs, pipe, q):
+    from oracle import oracle as O
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    cpu.clear(), cpu.set_light_direction(q[0:3]), cpu.set_camera(q[3:6], q[6:9], q[9:12])
+    err = cpu.render()
+    fb = cpu.get_frame_buffer()
+    cpu.close()
+    return err, fb
+
+
+def test_cli_time_based_loop(synthetic, tmp_path):
+    """`--seconds`: the reference's time-based frame loop (app.rs:166-247: angles advance by 3 rad/s times the frame
+    time, `FPS --- n` about once a second), every frame read back; the written frame is a frame of the orbit."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    out = str(tmp_path / "loop.png")
+    r = subprocess.run([sys.executable, "-m", "tiny_renderer_amd.cli", "--synthetic", "-s", "phong", "--width", "320",
+                        "--height", "240", "--seconds", "1.3", "--out", out], cwd=H.REPO, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fps = [int(l.split("---")[1]) for l in r.stdout.splitlines() if l.startswith("FPS ---")]
+    assert fps and all(f > 20 for f in fps), r.stdout[-500:]
+    got = np.array(Image.open(out).convert("RGB"))
+    assert got.shape == (240, 320, 3) and got.any()
 
 
 def test_pair_rcp_sqrt_exhaustive(built):

@@ -228,3 +228,22 @@ def test_png_writer_roundtrip(built, tmp_path):
         assert np.array_equal(np.array(Image.open(path).convert("RGB")), img)
     with pytest.raises(T.TinyRendererError):
         T.save_png(str(tmp_path / "no" / "dir.png"), img)
+
+
+def test_cli_ranks_are_started_as_a_module(tmp_path):
+    """`--gpus N` starts its ranks with torch.distributed.run as `-m tiny_renderer_amd.cli` (a plain script path has
+    no parent package: its relative imports fail in every rank) with the package's parent on PYTHONPATH, from any
+    working directory.  Here one rank is started the way launch_ranks builds the command, elsewhere, and must get
+    past its imports (no GPU needed: the hook returns before anything touches one)."""
+    import os
+    import subprocess
+    import sys
+    from tiny_renderer_amd.sharded import rank_command, rank_environment
+    cmd = rank_command(2, "tiny_renderer_amd.cli", ["--synthetic", "--gpus", "2"], 29517)
+    assert "-m" in cmd and cmd[cmd.index("-m", 3) + 1] == "tiny_renderer_amd.cli"
+    env = rank_environment()
+    env.update(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", TR_CLI_IMPORT_CHECK="1")
+    module_part = cmd[cmd.index("-m", 3):]          # what torch.distributed.run executes per rank
+    r = subprocess.run([sys.executable] + module_part, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "rank 1 of 2: imports ok" in r.stdout

@@ -24,6 +24,7 @@ TR_EXCHANGE_HANDLE_BYTES = 256
 TR_OPT_WINNER_TAP = 0x1
 TR_OPT_TILE_STAMPS = 0x2
 TR_OPT_NO_AUTO_GROUP = 0x4
+TR_OPT_TRUST_FRAME_BUFFERS = 0x8
 
 
 class TinyRendererError(RuntimeError):
@@ -101,6 +102,8 @@ SYMBOLS = {
     "tr_scene_profile_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int]),
     "tr_scene_profile_frame_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "tr_selftest_device_math": (C.c_int, [C.c_int, _FP, _FP, C.c_uint32] + [C.c_void_p] * 5),
+    "tr_selftest_shadow_fetch": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+                                 + [C.c_void_p] * 6),
     "tr_exchange_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(C.c_void_p)]),
     "tr_exchange_frame": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "tr_exchange_export": (C.c_int, [C.c_void_p, C.c_void_p]),

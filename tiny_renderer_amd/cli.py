@@ -40,7 +40,7 @@ def main(argv=None):
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         from .sharded import launch_ranks
-        return launch_ranks(args.gpus, os.path.abspath(__file__), list(argv) if argv is not None else sys.argv[1:])
+        return launch_ranks(args.gpus, "tiny_renderer_amd.cli", list(argv) if argv is not None else sys.argv[1:])
     world = int(world_env or "1")
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
@@ -62,6 +62,9 @@ def main(argv=None):
         import torch
         import torch.distributed as dist
         from .sharded import ShardedScene
+        if os.environ.get("TR_CLI_IMPORT_CHECK") == "1":   # test hook: a rank started the way launch_ranks starts it
+            print("rank %d of %d: imports ok" % (rank, world))
+            return 0
         if args.seconds > 0:
             # every rank must render the same frames: wall-clock driven angles would differ per process
             raise SystemExit("--seconds (the time-based loop) runs on one GPU: use --frames with --gpus")

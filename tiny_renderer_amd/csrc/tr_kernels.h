@@ -17,11 +17,11 @@ namespace tr {
 // FUSED one over a group of frames (tr_scene_render_frames): the workgroups of frame f take entry f of the
 // table; `a` (and `tile_count` / `order`) then only describe what the frames have in common -- mesh size,
 // tile grid, record layout, bin capacity -- to the launcher.  launch_order reads each frame's counters and
-// work list from the TILE kernel's table (TileArgs::tile_count_next is the frame's own counter set there).
+// work lists from the TILE kernel's table (TileArgs::tile_count / order / list_len).
 int launch_setup(int vs_kind, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st,
                  hipEvent_t start, hipEvent_t done);
-// Builds the tile kernel's work list from the counters k_setup filled (same stream, after it).
-int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkItem *order, uint32_t n_tiles,
+// Builds the tile kernel's work lists from the counters k_setup filled (same stream, after it) and zeroes them.
+int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkItem *order /* 8 x n_tiles */, uint32_t n_tiles,
                  const TileArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
 // tile_waves: 4, 8 or 16 wavefronts per tile workgroup (see tr_types.h); shared != 0: the waves share the
 // tile's bin and resolve through atomic keys instead of each owning a column of the tile (k_tile's
@@ -41,6 +41,10 @@ int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uin
 // rcp2 (which = 0) / sqrt2 (1) of tr_pk.h against '/' and sqrtf for the f32 bit patterns [first, first + count)
 int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned long long *n_bad, uint32_t *bad_bits,
                           hipStream_t st);
+// shadow_fetch (tr_shaders.h) on the device: through the fast-clear flags on `stale`, and plain on `plain`
+int launch_selftest_shadow(const float *plain, const float *stale, const uint32_t *sclean, uint32_t W, uint32_t H,
+                           const float *x, const float *y, uint32_t n, uint32_t *out_plain, uint32_t *out_flagged,
+                           uint32_t *err_plain, uint32_t *err_flagged, hipStream_t st);
 // 1 when the specular closure's powf reproduces the host libm's bit for bit (tr_powf.h)
 int specular_is_exact();
 int launch_depth_view(const float *src, uint8_t *dst, uint32_t W, uint32_t H, hipStream_t st);

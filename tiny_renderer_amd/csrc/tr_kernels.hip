@@ -1202,6 +1202,25 @@ __global__ __launch_bounds__(256) void k_selftest(const float *x, const float *d
     out_div_ref[i] = x[i] / d[i];
 }
 
+// tr_selftest_shadow_fetch: the DEVICE form of shadow_fetch (tr_shaders.h) on caller-chosen coordinates, once
+// through the fast-clear flags on a buffer whose flagged tiles hold stale values, once as a plain lookup in the
+// materialised buffer: value bits and error bits of both, for the host to compare.
+__global__ __launch_bounds__(256) void k_selftest_shadow(const float *plain, const float *stale, const uint32_t *sclean,
+                                                         uint32_t W, uint32_t H, const float *x, const float *y, uint32_t n,
+                                                         uint32_t *out_plain, uint32_t *out_flagged, uint32_t *err_plain,
+                                                         uint32_t *err_flagged)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t e0 = 0u, e1 = 0u;
+    const float a = shadow_fetch(plain, nullptr, W, H, make3(x[i], y[i], 0.0f), e0);
+    const float b = shadow_fetch(stale, sclean, W, H, make3(x[i], y[i], 0.0f), e1);
+    out_plain[i] = __float_as_uint(a);
+    out_flagged[i] = __float_as_uint(b);
+    err_plain[i] = e0;
+    err_flagged[i] = e1;
+}
+
 // tr_selftest_device_unary: rcp2 / sqrt2 (tr_pk.h) against the compiler's correctly rounded
 // 1.0f / x and sqrtf for every f32 whose bits lie in [first, first + count).
 __global__ __launch_bounds__(256) void k_selftest_unary(int which, uint32_t first, uint64_t count,
@@ -1442,6 +1461,17 @@ int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u3
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_selftest, dim3((n + 255u) / 256u), dim3(256), 0, st, x, d, n, out_u32, out_i32, out_u8,
                        out_div, out_div_ref);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_selftest_shadow(const float *plain, const float *stale, const uint32_t *sclean, uint32_t W, uint32_t H,
+                           const float *x, const float *y, uint32_t n, uint32_t *out_plain, uint32_t *out_flagged,
+                           uint32_t *err_plain, uint32_t *err_flagged, hipStream_t st)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_selftest_shadow, dim3((n + 255u) / 256u), dim3(256), 0, st, plain, stale, sclean, W, H, x, y, n,
+                       out_plain, out_flagged, err_plain, err_flagged);
     TR_LAUNCH_CHECK();
     return 0;
 }

@@ -188,6 +188,10 @@ struct tr_scene {
     // consumer the library cannot call back (an asynchronous read-back, or a caller's stream).
     unsigned long long *d_overflow_seq = nullptr;
     uint64_t observed_seq = 0;
+    // Passes below this number rendered frames into caller-provided buffers that the library can no longer
+    // render again (older frames of a tr_scene_render_frames call, frames of an automatic group before its last):
+    // a bin overflow among them is reported, like one in a frame that was handed on
+    uint64_t unreplayable_seq = 0;
     // The current targets (aliases: the memory belongs to the frame slots below, or to the caller)
     float *d_z = nullptr, *d_shadow = nullptr;
     uint32_t *d_sclean = nullptr;  // the shadow buffer's fast-clear flags (n_tiles_full)
@@ -310,10 +314,13 @@ void dev_free(T *&p)
 // the first time a buffer is seen; at most a handful of buffers are remembered).
 // The flag set of frame buffer `fb` (allocated zeroed = "content unknown" the first time a buffer is seen;
 // a few dozen buffers are remembered: a caller's double-buffered groups of frames, the scene's own slots).
-int fb_flags_for(tr_scene *s, uint8_t *fb, uint32_t **out)
+int fb_flags_for(tr_scene *s, uint8_t *fb, uint32_t **out, bool forget = false)
 {
     for (const tr_scene::FbFlags &f : s->fb_flags)
         if (f.fb == fb) {
+            // `forget`: a caller's buffer handed over again without TR_OPT_TRUST_FRAME_BUFFERS -- anybody may have
+            // written it since: "content unknown" (on the main stream: after the tile kernels that used the flags)
+            if (forget) HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
             *out = f.clean;
             return TR_OK;
         }
@@ -333,10 +340,19 @@ int fb_flags_for(tr_scene *s, uint8_t *fb, uint32_t **out)
     return TR_OK;
 }
 
-int select_fb_flags(tr_scene *s)
+// Is `fb` one of the scene's own colour buffers (whose remembered flags always hold)?
+bool own_frame_buffer(const tr_scene *s, const uint8_t *fb)
+{
+    for (const tr_scene::FrameSlot &fs : s->slots)
+        if (fs.fb == fb) return true;
+    return false;
+}
+
+int select_fb_flags(tr_scene *s, bool handed_over = false)
 {
     uint32_t *clean = nullptr;
-    int st = fb_flags_for(s, s->d_fb, &clean);
+    const bool forget = handed_over && !(s->flags & TR_OPT_TRUST_FRAME_BUFFERS) && !own_frame_buffer(s, s->d_fb);
+    int st = fb_flags_for(s, s->d_fb, &clean, forget);
     if (st != TR_OK) return st;
     // the winner tap is one buffer shared by all targets: its tiles were last written with another
     // target's frame, so a remembered "clean" says nothing about them
@@ -365,7 +381,7 @@ int slot_own_fb(tr_scene *s, int k, uint8_t **out)
 
 // Makes slot k the current set of targets; colour goes to `fb` (a caller's buffer) or, if null, to the
 // slot's own buffer.
-int use_slot(tr_scene *s, int k, uint8_t *fb)
+int use_slot(tr_scene *s, int k, uint8_t *fb, bool handed_over = false)
 {
     const tr_scene::FrameSlot &fs = s->slots[(size_t)k];
     s->cur_slot = k;
@@ -378,7 +394,7 @@ int use_slot(tr_scene *s, int k, uint8_t *fb)
         if (st != TR_OK) return st;
     }
     s->d_fb = fb;
-    return select_fb_flags(s);
+    return select_fb_flags(s, handed_over);
 }
 
 hipEvent_t take_event(tr_scene *s)
@@ -629,6 +645,14 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     }
     if (st != TR_OK) return st;
     // (the frame groups' bins follow bin_cap when their set is next used)
+    if (first_bad_seq < s->unreplayable_seq && first_bad_seq >= s->observed_seq) {
+        char buf[320];
+        snprintf(buf, sizeof buf,
+                 "triangle bins overflowed in a frame that went to a caller's buffer and cannot be rendered again (an older "
+                 "frame of tr_scene_render_frames, or of a fused group of per-frame renders): that buffer holds a truncated "
+                 "frame; the bins have been grown to %u records per tile: render it again", s->bin_cap);
+        return tr::fail(TR_E_BIN_OVERFLOW, buf);
+    }
     if (first_bad_seq < s->observed_seq) {
         char buf[320];
         snprintf(buf, sizeof buf,
@@ -697,6 +721,7 @@ int sync_and_status(tr_scene *s)
     if (err & DE_BIN_OVERFLOW) {
         int st = recover_from_overflow(s, first_bad);
         s->observed_seq = 0;  // everything issued so far has completed; later hand-offs count afresh
+        s->unreplayable_seq = 0;
         if (st != TR_OK) return st;
         st = submit_pending(s);
         if (st != TR_OK) return st;
@@ -706,6 +731,7 @@ int sync_and_status(tr_scene *s)
         if (err & DE_BIN_OVERFLOW) return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins overflowed twice");
     }
     s->observed_seq = 0;
+    s->unreplayable_seq = 0;
     s->quiescent = true;  // (whatever a getter queues next -- a view kernel, a copy -- it also waits for)
     if (host_status != TR_OK) return host_status;
     if (err & (DE_W_ZERO | DE_TEX_OOB | DE_SHADOW_OOB | DE_SINGULAR)) {
@@ -1025,7 +1051,7 @@ int submit_groups(tr_scene *s, bool all);
 // Queues the setup of g <= frames-per-group cleared frames, one launch per kernel and pass.  Frame j takes
 // light and camera from p[j], its targets from slot slot_of[j] and its colour buffer from fbs[j] (fbs == null:
 // the slot's own).  The tile kernels follow with submit_groups.
-int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int *slot_of, uint32_t g)
+int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int *slot_of, uint32_t g, bool forget_callers_buffers = false)
 {
     const PipelineDesc &pd = kPipelines[s->pipeline];
     const uint32_t np = (uint32_t)pd.n_passes;
@@ -1065,9 +1091,10 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
         memcpy(s->at, p[j].look_at, 12); memcpy(s->up, p[j].up, 12);
         const tr_scene::FrameSlot &slot = s->slots[(size_t)slot_of[j]];
         uint8_t *fb = fbs ? (uint8_t *)fbs[j] : nullptr;
+        const bool callers = fb != nullptr;
         if (!fb) st = slot_own_fb(s, slot_of[j], &fb);
         uint32_t *fbclean = nullptr;
-        if (st == TR_OK) st = fb_flags_for(s, fb, &fbclean);
+        if (st == TR_OK) st = fb_flags_for(s, fb, &fbclean, callers && forget_callers_buffers);
         for (uint32_t pi = 0; pi < np && st == TR_OK; pi++) {
             const PassDesc &pass = pd.pass[pi];
             const bool depth_pass = (pass.fs == FS_DEPTH);
@@ -1295,6 +1322,9 @@ int flush_deferred(tr_scene *s, bool hold_back)
             bool overwritten = false;
             for (uint32_t k = j + 1; k < g; k++) overwritten = overwritten || fr[k].fb == fr[j].fb;
             fbs[j] = overwritten ? nullptr : fr[j].fb;
+            // (such a frame can be seen in its buffer but not rendered again: only the last frame is replayed)
+            if (fbs[j] && !own_frame_buffer(s, (const uint8_t *)fbs[j]))
+                s->unreplayable_seq = s->pass_seq + (uint64_t)(j + 1u) * (uint64_t)kPipelines[s->pipeline].n_passes;
         }
     }
     st = run_group(s, params, fbs, slot_of, g);
@@ -1318,7 +1348,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     if (s->d_winner) {
         // the winner tap is a single buffer: frame by frame through the ordinary path, slots all the same
         for (uint32_t i = 0; i < n; i++) {
-            if ((st = use_slot(s, (int)(i % G), fbs ? (uint8_t *)fbs[i] : nullptr)) != TR_OK) return st;
+            if ((st = use_slot(s, (int)(i % G), fbs ? (uint8_t *)fbs[i] : nullptr, fbs != nullptr)) != TR_OK) return st;
             memcpy(s->light, p[i].light, 12); memcpy(s->from, p[i].look_from, 12);
             memcpy(s->at, p[i].look_at, 12); memcpy(s->up, p[i].up, 12);
             s->z_fb_cleared = s->shadow_cleared = true;
@@ -1329,7 +1359,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
         for (uint32_t j = 0; j < (uint32_t)GROUP_MAX; j++) slot_of[j] = (int)j;
         for (uint32_t i0 = 0; i0 < n; i0 += G) {
             const uint32_t g = n - i0 < G ? n - i0 : G;
-            st = run_group(s, p + i0, fbs ? fbs + i0 : nullptr, slot_of, g);
+            st = run_group(s, p + i0, fbs ? fbs + i0 : nullptr, slot_of, g, fbs && !(s->flags & TR_OPT_TRUST_FRAME_BUFFERS));
             if (st == TR_OK) st = submit_groups(s, false);
             if (st != TR_OK) {
                 // (a singular camera in frame i0 .. i0 + g - 1, or the device refused a launch): the groups before are
@@ -1359,6 +1389,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     s->tail.slot.resize(kept);
     for (uint32_t k = 0; k < kept; k++) s->tail.slot[k] = (int)((n - kept + k) % G);
     s->tail.first_seq = first_seq + (uint64_t)(n - kept) * np;
+    if (fbs && n > kept) s->unreplayable_seq = s->tail.first_seq;  // older frames' buffers: theirs for good
     s->last_was_group = true;
     s->last.valid = false;
     return TR_OK;
@@ -1709,6 +1740,39 @@ int tr_selftest_device_math(int device, const float *x, const float *d, uint32_t
     return st;
 }
 
+int tr_selftest_shadow_fetch(int device, uint32_t width, uint32_t height, const float *plain, const float *stale,
+                             const uint32_t *sclean, uint32_t n, const float *x, const float *y, uint32_t *out_plain,
+                             uint32_t *out_flagged, uint32_t *err_plain, uint32_t *err_flagged)
+{
+    if (!plain || !stale || !sclean || !x || !y || !out_plain || !out_flagged || !err_plain || !err_flagged || width == 0 ||
+        height == 0)
+        return tr::fail(TR_E_INVALID, "null argument");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    const size_t npx = (size_t)width * height;
+    const size_t n_tiles = (size_t)((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
+    const size_t bytes[9] = { npx * 4, npx * 4, n_tiles * 4, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4,
+                              (size_t)n * 4, (size_t)n * 4 };
+    const void *src[5] = { plain, stale, sclean, x, y };
+    void *buf[9] = {};
+    int st = TR_OK;
+    for (int i = 0; i < 9 && st == TR_OK; i++)
+        if (hipMalloc(&buf[i], bytes[i] ? bytes[i] : 4) != hipSuccess) st = tr::fail(TR_E_HIP, "hipMalloc failed");
+    for (int i = 0; i < 5 && st == TR_OK; i++)
+        if (hipMemcpy(buf[i], src[i], bytes[i], hipMemcpyHostToDevice) != hipSuccess) st = tr::fail(TR_E_HIP, "upload failed");
+    if (st == TR_OK) {
+        int rc = launch_selftest_shadow((const float *)buf[0], (const float *)buf[1], (const uint32_t *)buf[2], width, height,
+                                        (const float *)buf[3], (const float *)buf[4], n, (uint32_t *)buf[5], (uint32_t *)buf[6],
+                                        (uint32_t *)buf[7], (uint32_t *)buf[8], nullptr);
+        if (rc || hipDeviceSynchronize() != hipSuccess) st = tr::fail(TR_E_HIP, "self-test kernel failed");
+    }
+    void *outs[4] = { out_plain, out_flagged, err_plain, err_flagged };
+    for (int i = 0; i < 4 && st == TR_OK; i++)
+        if (hipMemcpy(outs[i], buf[5 + i], (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) st = tr::fail(TR_E_HIP, "download failed");
+    for (int i = 0; i < 9; i++)
+        if (buf[i]) (void)hipFree(buf[i]);
+    return st;
+}
+
 int tr_selftest_device_unary(int device, int which, int exp_lo, int exp_hi, uint64_t *n_tested, uint64_t *n_bad,
                              uint32_t bad_bits[16])
 {
@@ -1892,7 +1956,7 @@ int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
     HIP_TRY(hipSetDevice(s->device));
-    return use_slot(s, s->cur_slot, (uint8_t *)frame_buffer_device);
+    return use_slot(s, s->cur_slot, (uint8_t *)frame_buffer_device, true);
 }
 
 int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1)

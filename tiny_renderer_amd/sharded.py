@@ -20,34 +20,53 @@ import sys
 from .scene import Scene, band_rows
 
 
-def launch_ranks(n_gpus, script, argv):
-    """Starts `n_gpus` rank processes of `script` (one per GPU) with torch.distributed.run and returns
+def rank_environment():
+    """Environment of a rank process: the package's parent directory on PYTHONPATH (the ranks are started as
+    `-m tiny_renderer_amd.cli`, whatever the caller's working directory is), dmabuf IPC for RCCL."""
+    env = dict(os.environ)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    return env
+
+
+def rank_command(n_gpus, module, argv, port):
+    """The command that starts `n_gpus` ranks of `python -m module argv...`, one per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", module] + list(argv)
+
+
+def launch_ranks(n_gpus, module, argv):
+    """Starts `n_gpus` rank processes of `python -m module` (one per GPU) with torch.distributed.run and returns
     their exit code.  Must be called from a process that has not touched a GPU (no torch.cuda call):
     the ranks are children, nothing is exec'ed over an initialised process."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = rank_command(n_gpus, module, argv, port)
     sys.stderr.write("starting %d ranks: %s\n" % (n_gpus, " ".join(cmd)))
-    return subprocess.run(cmd, env=env).returncode
+    return subprocess.run(cmd, env=rank_environment()).returncode
 
 
-def any_rank(flag, device=None):
-    """True on every rank if `flag` is true on any (one tiny all-reduce).  Decisions that change how many
-    collectives a rank issues -- rendering a frame again after its bins overflowed -- must be taken
-    together, or the ranks fall out of step and the next collective never completes."""
+def worst_status(code, device=None):
+    """The smallest (most severe: error codes are negative) status over all ranks, one tiny all-reduce.  Decisions
+    that change how many collectives a rank issues -- rendering a frame again after its bins overflowed, giving
+    up on an error -- must be taken together, or the ranks fall out of step and the next collective never
+    completes."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return bool(flag)
+        return int(code)
     on_gpu = dist.get_backend() == "nccl"
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+    t = torch.tensor([int(code)], dtype=torch.int32,
                      device=("cuda:%d" % (torch.cuda.current_device() if device is None else device)) if on_gpu else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return bool(int(t.item()))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def any_rank(flag, device=None):
+    """True on every rank if `flag` is true on any."""
+    return worst_status(-1 if flag else 0, device) != 0
 
 
 class ShardedScene:
@@ -76,9 +95,11 @@ class ShardedScene:
         self._rendered = [torch.cuda.Event() for _ in range(2)]
         self._gathered = [torch.cuda.Event() for _ in range(2)]
         torch.cuda.synchronize(device)
+        # (the frame tensors are written by this scene and by the exchange of OTHER ranks' rows only: the scene may
+        # trust what it remembers about its own rows of them)
         self._scene = Scene(width, height, mesh, textures, shader_pipeline_name, device=device,
                             stream=self._render.cuda_stream, frame_buffer_device=self._fbs[0].data_ptr(),
-                            band_rows=self.band, **scene_kw)
+                            band_rows=self.band, trust_frame_buffers=True, **scene_kw)
         self._slot = 1          # the first frame goes to slot 0
         self._cleared = True    # Scene::new leaves cleared (zero-filled) targets
         self._used = [False, False]
@@ -123,7 +144,8 @@ class ShardedScene:
         self._last_group = None
 
     def render_frames(self, frames):
-        """Many frames per call (Scene.render_frames on every rank): each rank renders its band of a group of
+        """Many frames per call (Scene.render_frames on every rank); afterwards only the LAST frame is exposed
+        (get_frame_buffer): each rank renders its band of a group of
         frames by one launch of each kernel into a set of frame tensors of the group's size, and the bands
         of the group are exchanged frame by frame on the second stream while the next group renders into
         the other set.  Frame i is what clear(); set_light_direction; set_camera; render() gives; afterwards
@@ -176,14 +198,17 @@ class ShardedScene:
         from ._lib import TinyRendererError, TR_E_BIN_OVERFLOW
         for attempt in range(4):
             self._torch.cuda.synchronize()
-            overflow = False
+            message = ""
             try:
                 status = self._scene.sync()
             except TinyRendererError as e:
-                if e.code != TR_E_BIN_OVERFLOW:
-                    raise
-                overflow, status = True, e.code
-            if not any_rank(overflow):
+                status, message = e.code, str(e)
+            # every rank learns the most severe status of any rank and acts on THAT: a rank that raised on its own
+            # (a lookup out of range in one band only) would leave the others waiting in the next collective
+            worst = worst_status(status)
+            if worst != TR_E_BIN_OVERFLOW:
+                if worst < 0:
+                    raise TinyRendererError(worst, message if status == worst else "raised on another rank")
                 return status
             if not self._last_was_cleared:
                 raise TinyRendererError(TR_E_BIN_OVERFLOW, "bins overflowed during an accumulating render: clear and render again")
