@@ -512,7 +512,7 @@ def main():
             frames_in_launch = tile["frames"] / tile["launches"]
             bytes_launch = bytes_alg * frames_in_launch / world
             ach = bytes_launch / avg_s / 1e9
-            traffic, traffic_note = None, "not profiled"
+            traffic, traffic_note, entry = None, "not profiled", {}
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
                 try:
@@ -534,12 +534,20 @@ def main():
                         traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
                 except Exception as e:  # a malformed file must not take the bench down
                     traffic, traffic_note = None, "unreadable pmc_traffic.json: %s" % e
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+            physical = round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None
+            # the kernel's real limiter: what crosses HBM is a fraction of the algorithmic bytes (fast-clear and
+            # colour-clean flags), the busy tiles are bound by vector-instruction issue.  issue_frac = share of the
+            # launch's SIMD-cycles in which a vector instruction executes (SQ counters of this source, else null).
+            issue = entry.get("issue") if (traffic is not None and isinstance(entry, dict)) else None
+            roofline = {"bound": "valu_issue" if (physical is not None and physical < 0.3) else "hbm",
+                        "issue_frac": issue.get("issue_frac") if issue else None,
+                        "issue_source": issue.get("source") if issue else "SQ counters not collected on this source / workload",
+                        "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                         "traffic_source": traffic_note,
                         # what actually crosses the HBM interface (the algorithmic model also counts the
                         # z clear of empty tiles, which the fast-clear flags never write)
-                        "physical_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+                        "physical_frac": physical,
                         "limiter": "vector/scalar instruction issue of the tiles with polygons, not HBM "
                                    "(SQ counters under profiles/)",
                         "avg_launch_us": round(avg_s * 1e6, 2), "frames_per_launch": round(frames_in_launch, 3),

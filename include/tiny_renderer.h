@@ -162,12 +162,18 @@ int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out); /* needs TR_OPT_WINNER
 
 /* Streaming frames out (the reference hands every frame to its window, app.rs:213-218): enqueue
  * the device-to-host copy of the frame behind the renders issued so far and return at once; `rgb`
- * (3*W*H bytes, row 0 = top) holds the frame after tr_scene_sync().  With memory from
- * tr_host_alloc (page-locked) the copy runs at PCIe speed and the host is free meanwhile; a later
- * render is ordered after the copy. */
+ * (3*W*H bytes, row 0 = top) holds the frame after tr_scene_sync(); a later render is ordered after the copy.
+ * Into memory from tr_host_alloc (page-locked, mapped into the device) only what has to travel does: the scene
+ * knows which 128x16 tiles of the frame hold the cleared colour, and remembers per host buffer which tiles it
+ * has written as zeros there -- those are skipped (widths that are multiples of 16; three quarters of a
+ * 4096x4096 frame of the reference's model: 1.1 ms -> 0.3 ms per frame).  The buffer always ends up holding the
+ * complete frame.  A caller that WRITES into such a buffer between two read-backs says so with
+ * tr_scene_host_buffer_written (the scene then assumes nothing about its content); reading it needs nothing.
+ * Any other host memory receives the whole frame through the copy engine. */
 int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb);
-void *tr_host_alloc(size_t bytes); /* page-locked host memory, NULL on failure */
+void *tr_host_alloc(size_t bytes); /* page-locked host memory mapped into the device, NULL on failure */
 void tr_host_free(void *p);
+int tr_scene_host_buffer_written(tr_scene *s, void *p);
 
 /* Device-resident access for callers that keep the frame on the GPU. */
 int tr_scene_sync(tr_scene *s);                 /* wait for queued work; returns frame status */

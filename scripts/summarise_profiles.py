@@ -1,6 +1,6 @@
 """Turns gpurun_out/prof (scripts/collect_profiles.sh) into the files kept under profiles/.
 
-    python scripts/summarise_profiles.py [round-tag]     (default r02)
+    python scripts/summarise_profiles.py [round-tag]     (default r03)
 
 profiles/pmc_traffic.json is stamped with bench.source_fingerprint() of the tree it is run in: run it
 right after the GPU call, on the sources that were profiled; bench.py reports `roofline.traffic`
@@ -14,7 +14,7 @@ from bench import source_fingerprint  # noqa: E402
 
 src = os.path.join(REPO, "gpurun_out", "prof")
 dst = os.path.join(REPO, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 WORKLOADS = {  # tag of collect_profiles.sh -> (bench workload string, dominant kernel)
     "headline": ("diablo.obj, -s phong, 4096x4096", "k_tile"),
@@ -36,7 +36,7 @@ def one(pattern):
 def kernel_of(name):
     if "k_tile" in name:
         return "k_tile_depth" if "<7," in name.replace(" ", "") or "FS_DEPTH" in name else "k_tile"
-    for k in ("k_setup", "k_order_count", "k_order_place", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
+    for k in ("k_setup", "k_order", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
         if k in name:
             return k
     return name[:48]
@@ -94,6 +94,19 @@ with open(os.path.join(dst, tag + "_pmc_fetch_write.csv"), "w") as f:
 json.dump(db, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 sq = counters("sq_*")
+# Vector-issue share of the headline's tile kernel: SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD executes a
+# vector instruction, summed over the 1 024 SIMDs; the launch lasted GRBM_GUI_ACTIVE / 8 cycles (the counter is summed
+# over the 8 XCDs: MI355X_MICROARCH.md, DVFS).  bench.py reports it as roofline.issue_frac while the fingerprint matches.
+head = db["workloads"].get(WORKLOADS["headline"][0])
+kt = sq.get("k_tile", {})
+if head is not None and kt.get("SQ_ACTIVE_INST_VALU") and kt.get("GRBM_GUI_ACTIVE"):
+    launch_cycles = kt["GRBM_GUI_ACTIVE"] / 8.0
+    head["issue"] = {"SQ_INSTS_VALU": kt.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": kt.get("SQ_INSTS_SALU"),
+                     "SQ_ACTIVE_INST_VALU_quad_cycles": kt["SQ_ACTIVE_INST_VALU"], "GRBM_GUI_ACTIVE": kt["GRBM_GUI_ACTIVE"],
+                     "launch_cycles": launch_cycles, "simds": 1024,
+                     "issue_frac": round(4.0 * kt["SQ_ACTIVE_INST_VALU"] / (1024.0 * launch_cycles), 4),
+                     "source": "profiles/%s_pmc_sq_4096_phong.json" % tag}
+    json.dump(db, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 json.dump({k: {c: round(v, 1) for c, v in cs.items()} for k, cs in sq.items() if k.startswith("k_")},
           open(os.path.join(dst, tag + "_pmc_sq_4096_phong.json"), "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, tag + "_bench_4096_phong.log")).read().strip().splitlines()[-1][:600])

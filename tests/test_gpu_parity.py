@@ -248,6 +248,50 @@ def test_async_frame_readback(small_synthetic):
     gpu.close()
 
 
+def test_sparse_read_back_orbit(diablo):
+    """The reference hands every frame to its window (app.rs:213-218).  Into page-locked buffers only the tiles
+    that are not zeros on both sides cross PCIe (k_read_back): the camera orbits over twelve frames read back
+    alternately into two buffers -- tiles that fill, tiles that EMPTY again (they must be re-zeroed in the buffer
+    that still holds an older frame), a frame read into a buffer the caller has scribbled on -- and every host
+    frame is the oracle's."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = diablo
+    W, Hh, n = 1024, 1024, 12
+    gpu = T.Scene(W, Hh, mesh, texs, "phong")
+    cpu = O.Scene(W, Hh, mesh, texs, "phong")
+    pinned = [gpu.pinned_frame() for _ in range(2)]
+    for b in pinned:
+        b[...] = 99                                   # unknown content to begin with
+    kept = []
+    for f in range(n):
+        ca = 0.55 * f
+        for s in (gpu, cpu):
+            s.clear(), s.set_light_direction(H.light(0.3)), s.set_camera(*H.camera(ca)), s.render()
+        if f == 7:
+            pinned[f % 2][100:200] = 55               # the caller writes into its buffer ...
+            gpu.host_buffer_written(pinned[f % 2])    # ... and says so
+        gpu.get_frame_buffer_async(pinned[f % 2])
+        if f % 2 == 1 or f == n - 1:
+            assert gpu.sync() == 0                    # two frames in flight at a time
+            for k in ((f - 1, f) if f % 2 == 1 else (f,)):
+                kept.append((k, pinned[k % 2].copy()))
+        want = cpu.get_frame_buffer()
+        if f % 2 == 1 or f == n - 1:
+            got = dict(kept)[f]
+            assert np.array_equal(got, want), "frame %d: %d pixels differ" % (f, int((got != want).any(-1).sum()))
+        else:
+            first_of_pair = want
+    # (the first frame of each pair is checked through the second buffer one frame later: above only the second
+    # and the last are compared with the oracle at the time; do all of them now)
+    cpu2 = O.Scene(W, Hh, mesh, texs, "phong")
+    for k, got in kept:
+        cpu2.clear(), cpu2.set_light_direction(H.light(0.3)), cpu2.set_camera(*H.camera(0.55 * k)), cpu2.render()
+        assert np.array_equal(got, cpu2.get_frame_buffer()), "frame %d" % k
+    assert len(kept) == n
+    gpu.close()
+
+
 def test_depth_views(small_synthetic):
     """get_z_buffer / get_shadow_buffer (scene.rs:101-125)."""
     mesh, texs = small_synthetic

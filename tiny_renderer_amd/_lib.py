@@ -86,6 +86,7 @@ SYMBOLS = {
     "tr_scene_get_frame_buffer_async": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_host_alloc": (C.c_void_p, [C.c_size_t]),
     "tr_host_free": (None, [C.c_void_p]),
+    "tr_scene_host_buffer_written": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_get_z_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_get_shadow_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_scene_read_z_f32": (C.c_int, [C.c_void_p, C.c_void_p]),

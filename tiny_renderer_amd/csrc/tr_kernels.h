@@ -29,6 +29,10 @@ int launch_order(uint32_t *tile_count /* n_tiles counters + 16 words */, WorkIte
 int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
                 uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);
+// The band's tiles of frame buffer `fb` into the page-locked host buffer `host` (device address of it), skipping the
+// tiles that are zeros on both sides (fb_clean: the target's colour-clean flags; host_clean: the host buffer's own)
+int launch_read_back(const uint8_t *fb, uint8_t *host, const uint32_t *fb_clean, uint32_t *host_clean, const DevFrame &frame,
+                     hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
                     uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st);
 // Peer exchange flags (tr_exchange.cpp): system-scope store of a generation number; waits that poll

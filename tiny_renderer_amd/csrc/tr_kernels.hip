@@ -1187,6 +1187,35 @@ __global__ __launch_bounds__(256) void k_depth_view(const float *src, uint8_t *d
     }
 }
 
+// Streaming a frame out to the host (app.rs:213-218 hands every frame to the window): one workgroup per tile of
+// the scene's band writes the tile's rows straight into the page-locked HOST buffer -- or nothing at all: a tile
+// whose colour-clean flag is up holds the cleared colour on the device, and if the host buffer's own flag says
+// the tile was zeros the last time it was written there, nothing has to cross PCIe (three quarters of a
+// 4096^2 frame of the reference's model).  `host_clean` belongs to (scene, host buffer); 16-byte pieces, so
+// the launcher requires width % 16 == 0.
+__global__ __launch_bounds__(256) void k_read_back(const uint8_t *__restrict__ fb, uint8_t *__restrict__ host,
+                                                   const uint32_t *__restrict__ fb_clean, uint32_t *host_clean, DevFrame frame)
+{
+    const uint32_t t = blockIdx.x;
+    const bool zeros = fb_clean[t] != 0u;
+    const bool host_zeros = host_clean[t] != 0u;
+    __syncthreads();  // (every thread has read the host flag before thread 0 changes it)
+    if (zeros && host_zeros) return;
+    const int32_t W = (int32_t)frame.width, H = (int32_t)frame.height;
+    const int32_t x0 = (int32_t)(t % frame.ntx) * TILE_W, y0 = (frame.ty_base + (int32_t)(t / frame.ntx)) * TILE_H;
+    // TILE_H rows x 24 pieces of 16 B
+    for (uint32_t c = threadIdx.x; c < (uint32_t)TILE_H * 24u; c += 256u) {
+        const int32_t y = y0 + (int32_t)(c / 24u);
+        const int32_t xb = x0 * 3 + (int32_t)(c % 24u) * 16;
+        if (xb < W * 3 && y >= frame.band_y0 && y < frame.band_y1) {
+            const size_t at = (size_t)(H - 1 - y) * W * 3 + xb;
+            const uint4 v = zeros ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4 *>(fb + at);
+            *reinterpret_cast<uint4 *>(host + at) = v;
+        }
+    }
+    if (threadIdx.x == 0u) host_clean[t] = zeros ? 1u : 0u;
+}
+
 // tr_selftest_device_math: the device forms of the casts and of the shared-reciprocal division,
 // applied to caller-chosen operands so the host can compare them with its own.
 __global__ __launch_bounds__(256) void k_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32,
@@ -1461,6 +1490,17 @@ int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u3
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_selftest, dim3((n + 255u) / 256u), dim3(256), 0, st, x, d, n, out_u32, out_i32, out_u8,
                        out_div, out_div_ref);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_read_back(const uint8_t *fb, uint8_t *host, const uint32_t *fb_clean, uint32_t *host_clean, const DevFrame &frame,
+                     hipStream_t st)
+{
+    const uint32_t n_tiles = frame.ntx * frame.nty;
+    if (n_tiles == 0) return 0;
+    if (frame.width % 16u) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_read_back, dim3(n_tiles), dim3(256), 0, st, fb, host, fb_clean, host_clean, frame);
     TR_LAUNCH_CHECK();
     return 0;
 }

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,16 @@ using namespace tr;
     } while (0)
 
 namespace {
+
+// Page-locked host buffers handed out by tr_host_alloc: host address -> {bytes, device address of the mapping}
+struct HostAlloc {
+    size_t bytes;
+    void *device;
+    uint64_t serial;  // (an address can come back from a later allocation: what a scene remembers is about THIS one)
+};
+std::mutex g_host_mutex;
+uint64_t g_host_serial = 0;
+std::map<void *, HostAlloc> g_host_allocs;
 
 struct PassDesc {
     int prepare_kind;  // 0 default_prepare, 1 shadow_pass_prepare_1, 2 shadow_pass_prepare_2
@@ -262,6 +273,14 @@ struct tr_scene {
     };
     std::vector<FbFlags> fb_flags;
     uint32_t *d_fbclean = nullptr;  // the current target's set
+    // Sparse read-back (tr_scene_get_frame_buffer_async into tr_host_alloc memory): per host buffer, which tiles of it
+    // hold zeros since this scene last wrote them there (device memory, updated by k_read_back)
+    struct HostFlags {
+        void *host;
+        uint64_t serial;
+        uint32_t *clean;
+    };
+    std::vector<HostFlags> host_flags;
     uint64_t *d_stamps = nullptr;
     uint32_t *d_err = nullptr;
     // page-locked host word the kernels set beside d_err (TileArgs::alarm), and its device address
@@ -1480,6 +1499,7 @@ void destroy(tr_scene *s)
     dev_free(s->d_view);
     dev_free(s->d_winner);
     for (tr_scene::FbFlags &f : s->fb_flags) dev_free(f.clean);
+    for (tr_scene::HostFlags &f : s->host_flags) dev_free(f.clean);
     dev_free(s->d_stamps);
     dev_free(s->d_err);
     if (s->h_alarm) (void)hipHostFree((void *)s->h_alarm);
@@ -2006,8 +2026,45 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
     if (st != TR_OK) return st;
     st = submit_pending(s);
     if (st != TR_OK) return st;
-    // same stream as the tile kernels: after the frame, before the next one overwrites it
-    HIP_TRY(hipMemcpyAsync(rgb, s->d_fb, (size_t)s->width * s->height * 3, hipMemcpyDeviceToHost, s->stream));
+    const size_t bytes = (size_t)s->width * s->height * 3;
+    // same stream as the tile kernels: after the frame, before the next one overwrites it.  Into memory from
+    // tr_host_alloc only the tiles that are not zeros on both sides travel (k_read_back); any other buffer gets
+    // the whole frame from the copy engine.
+    void *mapped = nullptr;
+    uint64_t serial = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        auto it = g_host_allocs.find(rgb);
+        if (it != g_host_allocs.end() && it->second.bytes >= bytes) {
+            mapped = it->second.device;
+            serial = it->second.serial;
+        }
+    }
+    if (mapped && s->width % 16u == 0u && s->d_fbclean) {
+        uint32_t *host_clean = nullptr;
+        for (tr_scene::HostFlags &f : s->host_flags)
+            if (f.host == rgb) {
+                if (f.serial != serial) {  // the address of a buffer that has been freed: another buffer now
+                    HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
+                    f.serial = serial;
+                }
+                host_clean = f.clean;
+            }
+        if (!host_clean) {
+            if (s->host_flags.size() >= 64u) {  // (a caller that cycles through many buffers: forget the oldest)
+                HIP_TRY(hipStreamSynchronize(s->stream));
+                dev_free(s->host_flags.front().clean);
+                s->host_flags.erase(s->host_flags.begin());
+            }
+            if ((st = dev_alloc(&host_clean, (size_t)s->n_tiles))) return st;
+            HIP_TRY(hipMemsetAsync(host_clean, 0, (size_t)s->n_tiles * 4, s->stream));  // content of the buffer unknown
+            s->host_flags.push_back({ rgb, serial, host_clean });
+        }
+        int rc = launch_read_back(s->d_fb, (uint8_t *)mapped, s->d_fbclean, host_clean, s->frame, s->stream);
+        if (rc) return launch_status(rc, "k_read_back");
+    } else {
+        HIP_TRY(hipMemcpyAsync(rgb, s->d_fb, bytes, hipMemcpyDeviceToHost, s->stream));
+    }
     s->quiescent = false;
     // every pass issued so far is now in a consumer's hands: a bin overflow among them can no longer
     // be repaired by rendering again, and tr_scene_sync will say so (TR_E_BIN_OVERFLOW)
@@ -2017,14 +2074,33 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
 
 void *tr_host_alloc(size_t bytes)
 {
-    void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    void *p = nullptr, *d = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped) != hipSuccess) return nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) d = nullptr;
+    if (d) {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        g_host_allocs[p] = { bytes, d, ++g_host_serial };
+    }
     return p;
 }
 
 void tr_host_free(void *p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        g_host_allocs.erase(p);
+    }
+    (void)hipHostFree(p);
+}
+
+int tr_scene_host_buffer_written(tr_scene *s, void *p)
+{
+    if (!s || !p) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    for (const tr_scene::HostFlags &f : s->host_flags)
+        if (f.host == p) HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
+    return TR_OK;
 }
 
 int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb)

@@ -159,6 +159,11 @@ class Scene:
         check(load_library().tr_scene_get_frame_buffer_async(self._h, out.ctypes.data))
         return out
 
+    def host_buffer_written(self, out):
+        """Tells the scene that the caller has written into a pinned_frame() array (it then assumes nothing about
+        the array's content at the next get_frame_buffer_async)."""
+        check(load_library().tr_scene_host_buffer_written(self._h, out.ctypes.data))
+
     def get_z_buffer(self, strict=True):
         return self._image("tr_scene_get_z_buffer", strict)
 
