@@ -41,7 +41,8 @@ enum {
     TR_E_FORMAT = -8,           /* unsupported OBJ / TGA content */
     TR_E_BIN_OVERFLOW = -9,     /* triangle-bin capacity exceeded; raise tr_options.bin_capacity */
     TR_E_NOMEM = -10,
-    TR_E_EXCHANGE = -11         /* multi-GPU frame exchange: a peer's band did not arrive */
+    TR_E_EXCHANGE = -11,        /* multi-GPU frame exchange: a peer's band did not arrive */
+    TR_E_RCCL = -12             /* RCCL backend of the frame exchange: librccl missing or a collective failed */
 };
 
 /* obj::raw::RawObj as the path reads it (util.rs:25-31, shader.rs:136-147,363-367,
@@ -208,6 +209,18 @@ int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row
 #define TR_EXCHANGE_HANDLE_BYTES 256
 typedef struct tr_exchange tr_exchange;
 int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, tr_exchange **out);
+/* The same exchange with a choice of transport.  TR_EXCHANGE_PEER: the copies described above (tr_exchange_create).
+ * TR_EXCHANGE_RCCL (north_star: "RCCL all-gather of the final framebuffer over xGMI"): connect builds
+ * an RCCL communicator owned by the exchange (rank 0's record carries the ncclUniqueId: the host's rendezvous only
+ * moves the 256-byte records, as for the peer transport; every rank must be inside tr_exchange_connect at the same
+ * time) and tr_exchange_all_gather is ONE in-place ncclAllGather on `hip_stream`; the ranks' byte ranges must then be
+ * equal pieces of one range, in rank order -- tr_band_rows with a height the ranks divide.  librccl is loaded when
+ * such an exchange is created; failures are TR_E_RCCL.  A Rust (or C) host needs no torch for either. */
+#define TR_EXCHANGE_PEER 0
+#define TR_EXCHANGE_RCCL 1
+int tr_exchange_create_backend(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, int backend,
+                               tr_exchange **out);
+uint64_t tr_exchange_bytes_sent(tr_exchange *x); /* bytes this rank has pushed to its peers since the exchange was created */
 void *tr_exchange_frame(tr_exchange *x, uint32_t slot);
 int tr_exchange_export(tr_exchange *x, void *record /* TR_EXCHANGE_HANDLE_BYTES */);
 int tr_exchange_connect(tr_exchange *x, const void *records /* n_ranks * TR_EXCHANGE_HANDLE_BYTES */);

@@ -878,6 +878,20 @@ def test_sharded_scene_render_frames(built):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout + r.stderr)[-3000:]
 
 
+def test_rccl_exchange_behind_the_c_abi(built):
+    """The RCCL backend of tr_exchange_* (the library owns the communicator: SURVEY.md 8b / 8e) with one rank, in
+    its own process and without torch: tests/rccl_exchange_worker.py."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "tests", "rccl_exchange_worker.py")], env=env, cwd=H.REPO,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout + r.stderr)[-3000:]
+
+
 def test_peer_exchange_two_processes_one_gpu(diablo):
     """The library's own frame exchange (tr_exchange_*: HIP IPC mapped frame slots, concurrent DMA-engine
     band copies, generation flags) with TWO rank processes sharing this box's one GPU: bench.py's N = 2

@@ -19,6 +19,9 @@ TR_E_FORMAT = -8
 TR_E_BIN_OVERFLOW = -9
 TR_E_NOMEM = -10
 TR_E_EXCHANGE = -11
+TR_E_RCCL = -12
+TR_EXCHANGE_PEER = 0
+TR_EXCHANGE_RCCL = 1
 TR_EXCHANGE_HANDLE_BYTES = 256
 
 TR_OPT_WINNER_TAP = 0x1
@@ -106,6 +109,8 @@ SYMBOLS = {
     "tr_selftest_shadow_fetch": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
                                  + [C.c_void_p] * 6),
     "tr_exchange_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tr_exchange_create_backend": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "tr_exchange_bytes_sent": (C.c_uint64, [C.c_void_p]),
     "tr_exchange_frame": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "tr_exchange_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -18,11 +18,19 @@
 // with s_sleep and give up after ten seconds (TR_E_EXCHANGE instead of a hung GPU).  All n - 1 band
 // copies leave at once: xGMI is point to point, each of the 7 links carries one band.
 //
+// Second backend, TR_EXCHANGE_RCCL ("ncclAllGather(sendbuf = band, recvbuf = full frame) in
+// place"; north_star's RCCL all-gather for a host that is not Python): the same calls, but connect() builds an RCCL
+// communicator -- rank 0's record carries the ncclUniqueId -- and all_gather is one in-place ncclAllGather on the
+// caller's stream.  librccl is opened with dlopen when such an exchange is created: a single-GPU user of the
+// library needs no RCCL.
+//
 // Not in the reference (single process, single thread); replaces nothing of it.  Selected with
 // `bench.py --exchange peer`; covered on one GPU by two processes sharing the device
 // (tests/test_gpu_parity.py::test_peer_exchange_two_processes_one_gpu) -- cross-GPU runs are the
 // driver's (8-GPU node).
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -48,9 +56,52 @@ constexpr uint32_t MAX_RANKS = 64;
 struct Blob {
     uint32_t magic, rank, n_ranks, n_slots;
     uint64_t frame_bytes;
-    hipIpcMemHandle_t frame[MAX_SLOTS];
-    hipIpcMemHandle_t flags;
+    union {
+        struct {
+            hipIpcMemHandle_t frame[MAX_SLOTS];
+            hipIpcMemHandle_t flags;
+        };
+        ncclUniqueId rccl_id;  // TR_EXCHANGE_RCCL: rank 0's record carries the communicator's id
+    };
 };
+
+// librccl, resolved when the first RCCL exchange is created
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.lib) return TR_OK;
+    void *lib = nullptr;
+    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return tr::fail(TR_E_RCCL, std::string("librccl could not be loaded: ") + dlerror());
+    Rccl r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(lib, "ncclCommGetAsyncError");
+    r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommGetAsyncError || !r.AllGather || !r.GetErrorString)
+        return tr::fail(TR_E_RCCL, "librccl lacks an expected symbol");
+    r.lib = lib;
+    g_rccl = r;
+    return TR_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return tr::fail(TR_E_RCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
 static_assert(sizeof(Blob) <= TR_EXCHANGE_HANDLE_BYTES, "blob must fit the published size");
 
 // flag block of one rank (uncached): [kind][slot][peer] generation counters, plus an error word
@@ -74,9 +125,13 @@ struct tr_exchange {
     std::vector<hipEvent_t> copy_done;             // [rank]
     hipEvent_t fork = nullptr;
     uint32_t generation[MAX_SLOTS] = {};
+    uint64_t bytes_sent = 0;  // bytes this rank has pushed to its peers so far
     uint32_t **d_wait_list = nullptr;  // device array of flag pointers for the arrival wait: [slot][peer]
     uint32_t **d_open_list = nullptr;  // ... and of the peers' "open" flags this rank stores into: [slot][peer]
     bool connected = false;
+    int backend = TR_EXCHANGE_PEER;
+    ncclComm_t comm = nullptr;     // TR_EXCHANGE_RCCL
+    ncclUniqueId rccl_id = {};     // ... rank 0's, published with its record
     uint64_t timeout_ticks = 1000000000ull;  // 10 s of the 100 MHz wall clock; TR_EXCHANGE_TIMEOUT_MS overrides (tests)
 };
 
@@ -84,8 +139,19 @@ extern "C" {
 
 int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, tr_exchange **out)
 {
+    return tr_exchange_create_backend(device, n_ranks, rank, n_slots, frame_bytes, TR_EXCHANGE_PEER, out);
+}
+
+int tr_exchange_create_backend(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, size_t frame_bytes, int backend,
+                               tr_exchange **out)
+{
     if (!out) return tr::fail(TR_E_INVALID, "null out pointer");
     *out = nullptr;
+    if (backend != TR_EXCHANGE_PEER && backend != TR_EXCHANGE_RCCL) return tr::fail(TR_E_INVALID, "unknown exchange backend");
+    if (backend == TR_EXCHANGE_RCCL) {
+        int st = load_rccl();
+        if (st != TR_OK) return st;
+    }
     if (n_ranks == 0 || n_ranks > MAX_RANKS || rank >= n_ranks || n_slots == 0 || n_slots > MAX_SLOTS || frame_bytes == 0)
         return tr::fail(TR_E_INVALID, "tr_exchange_create: need rank < n_ranks <= 64, 1..2 slots, a non-empty frame");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
@@ -96,6 +162,7 @@ int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_s
     x->rank = rank;
     x->n_slots = n_slots;
     x->frame_bytes = frame_bytes;
+    x->backend = backend;
     if (const char *ms = getenv("TR_EXCHANGE_TIMEOUT_MS")) {
         const long v = atol(ms);
         if (v > 0) x->timeout_ticks = (uint64_t)v * 100000ull;
@@ -112,6 +179,13 @@ int tr_exchange_create(int device, uint32_t n_ranks, uint32_t rank, uint32_t n_s
     if (e != hipSuccess) {
         tr_exchange_destroy(x);
         return tr::fail(TR_E_HIP, std::string("tr_exchange_create: ") + hipGetErrorString(e));
+    }
+    if (backend == TR_EXCHANGE_RCCL && rank == 0u) {
+        ncclResult_t r = g_rccl.GetUniqueId(&x->rccl_id);
+        if (r != ncclSuccess) {
+            tr_exchange_destroy(x);
+            return tr::fail(TR_E_RCCL, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+        }
     }
     *out = x;
     return TR_OK;
@@ -130,8 +204,13 @@ int tr_exchange_export(tr_exchange *x, void *blob)
     b.n_ranks = x->n_ranks;
     b.n_slots = x->n_slots;
     b.frame_bytes = x->frame_bytes;
-    for (uint32_t s = 0; s < x->n_slots; s++) HIP_TRY(hipIpcGetMemHandle(&b.frame[s], x->frame[s]));
-    HIP_TRY(hipIpcGetMemHandle(&b.flags, x->flags));
+    if (x->backend == TR_EXCHANGE_RCCL) {
+        b.magic = 0x54525243u;  // "TRRC"
+        b.rccl_id = x->rccl_id;  // (meaningful in rank 0's record only)
+    } else {
+        for (uint32_t s = 0; s < x->n_slots; s++) HIP_TRY(hipIpcGetMemHandle(&b.frame[s], x->frame[s]));
+        HIP_TRY(hipIpcGetMemHandle(&b.flags, x->flags));
+    }
     memset(blob, 0, TR_EXCHANGE_HANDLE_BYTES);
     memcpy(blob, &b, sizeof b);
     return TR_OK;
@@ -142,6 +221,22 @@ int tr_exchange_connect(tr_exchange *x, const void *blobs)
     if (!x || !blobs) return tr::fail(TR_E_INVALID, "null argument");
     if (x->connected) return tr::fail(TR_E_INVALID, "tr_exchange_connect: already connected");
     HIP_TRY(hipSetDevice(x->device));
+    if (x->backend == TR_EXCHANGE_RCCL) {
+        // every rank's record must describe the same exchange; rank 0's carries the id.  Collective: all ranks
+        // are inside ncclCommInitRank together.
+        ncclUniqueId id = {};
+        for (uint32_t p = 0; p < x->n_ranks; p++) {
+            Blob b;
+            memcpy(&b, (const uint8_t *)blobs + (size_t)p * TR_EXCHANGE_HANDLE_BYTES, sizeof b);
+            if (b.magic != 0x54525243u || b.rank != p || b.n_ranks != x->n_ranks || b.n_slots != x->n_slots ||
+                b.frame_bytes != x->frame_bytes)
+                return tr::fail(TR_E_INVALID, "tr_exchange_connect: the peers' records do not describe the same RCCL exchange");
+            if (p == 0u) id = b.rccl_id;
+        }
+        RCCL_TRY(g_rccl.CommInitRank(&x->comm, (int)x->n_ranks, id, (int)x->rank));
+        x->connected = true;
+        return TR_OK;
+    }
     for (uint32_t s = 0; s < x->n_slots; s++) x->peer_frame[s].assign(x->n_ranks, nullptr);
     x->peer_flags.assign(x->n_ranks, nullptr);
     x->copy_stream.assign(x->n_ranks, nullptr);
@@ -185,7 +280,17 @@ int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t 
         return tr::fail(TR_E_INVALID, "tr_exchange_all_gather: slot or byte range outside the frame");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(x->device));
-    const uint32_t g = ++x->generation[slot];
+    if (x->backend == TR_EXCHANGE_RCCL) {
+        // in place: rank r's `bytes` at `offset` are piece r of n equal pieces that start at offset - r * bytes
+        const size_t before = (size_t)x->rank * bytes;
+        if (offset < before || offset - before + (size_t)x->n_ranks * bytes > x->frame_bytes)
+            return tr::fail(TR_E_INVALID, "tr_exchange_all_gather (RCCL): the ranks' ranges must be equal pieces of one range of "
+                                          "the frame, in rank order (tr_band_rows with a height the ranks divide)");
+        RCCL_TRY(g_rccl.AllGather(x->frame[slot] + offset, x->frame[slot] + (offset - before), bytes, ncclUint8, x->comm, stream));
+        x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);
+        return TR_OK;
+    }
+    const uint32_t g = x->generation[slot] + 1u;
     const uint32_t r = x->rank;
     // 1. my slot is open for generation g -- ordered after everything the caller queued on `stream`
     //    (its consumer of the slot's previous content, and the render of this band)
@@ -215,13 +320,25 @@ int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t 
                                            x->flags + FlagIndex::error(), x->timeout_ticks, stream);
         if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
     }
+    // (only now: a call that failed half way has not used up the generation its peers are waiting for -- the
+    // exchange is unusable after such a failure, but the next call does not pretend to be a later generation)
+    x->generation[slot] = g;
+    x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);
     return TR_OK;
 }
+
+uint64_t tr_exchange_bytes_sent(tr_exchange *x) { return x ? x->bytes_sent : 0u; }
 
 int tr_exchange_status(tr_exchange *x)
 {
     if (!x) return tr::fail(TR_E_INVALID, "null exchange");
     HIP_TRY(hipSetDevice(x->device));
+    if (x->backend == TR_EXCHANGE_RCCL) {
+        ncclResult_t async = ncclSuccess;
+        if (x->comm) RCCL_TRY(g_rccl.CommGetAsyncError(x->comm, &async));
+        if (async != ncclSuccess) return tr::fail(TR_E_RCCL, std::string("RCCL communicator: ") + g_rccl.GetErrorString(async));
+        return TR_OK;
+    }
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, x->flags + FlagIndex::error(), 4, hipMemcpyDeviceToHost));
     if (err) return tr::fail(TR_E_EXCHANGE, "a peer's band did not arrive in time (the rank is gone or out of step)");
@@ -242,6 +359,7 @@ void tr_exchange_destroy(tr_exchange *x)
     if (!x) return;
     (void)hipSetDevice(x->device);
     (void)hipDeviceSynchronize();
+    if (x->comm) (void)g_rccl.CommDestroy(x->comm);
     for (uint32_t p = 0; p < x->peer_flags.size(); p++) {
         if (p == x->rank) continue;
         for (uint32_t s = 0; s < x->n_slots; s++)

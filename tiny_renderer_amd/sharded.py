@@ -244,15 +244,18 @@ class PeerExchange:
     `dist` (any initialised torch.distributed backend, gloo is enough) only carries the 256-byte
     connection records."""
 
-    def __init__(self, n_slots, frame_bytes, rank, world, device):
+    def __init__(self, n_slots, frame_bytes, rank, world, device, backend="peer"):
+        """backend: "peer" (IPC-mapped slots, DMA-engine band copies) or "rccl" (the library's own RCCL communicator:
+        one in-place ncclAllGather per call; `dist` still only carries the records)."""
         import ctypes as C
         import torch.distributed as dist
-        from ._lib import check, load_library, TR_EXCHANGE_HANDLE_BYTES
+        from ._lib import check, load_library, TR_EXCHANGE_HANDLE_BYTES, TR_EXCHANGE_PEER, TR_EXCHANGE_RCCL
         L = load_library()
         self._L, self._check = L, check
         self.n_slots, self.frame_bytes, self.rank, self.world = n_slots, frame_bytes, rank, world
         h = C.c_void_p()
-        check(L.tr_exchange_create(device, world, rank, n_slots, frame_bytes, C.byref(h)))
+        check(L.tr_exchange_create_backend(device, world, rank, n_slots, frame_bytes,
+                                           {"peer": TR_EXCHANGE_PEER, "rccl": TR_EXCHANGE_RCCL}[backend], C.byref(h)))
         self._h = h
         mine = C.create_string_buffer(TR_EXCHANGE_HANDLE_BYTES)
         check(L.tr_exchange_export(h, mine))
@@ -279,6 +282,9 @@ class PeerExchange:
 
     def status(self):
         return self._check(self._L.tr_exchange_status(self._h))
+
+    def bytes_sent(self):
+        return int(self._L.tr_exchange_bytes_sent(self._h))
 
     def close(self):
         if self._h:
