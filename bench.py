@@ -222,12 +222,19 @@ def main():
         fbs, fb_ptr = None, [None]  # N = 1: the scene's own frame slots
     torch.cuda.synchronize()
     grouped = (not use_dist) and args.submit == "frames"
-    scene = T.Scene(W, H, mesh, texs, pipe, device=device_index,
+    # N > 1 through RCCL: every rank renders its band of a GROUP of frames per kernel launch and the bands are
+    # exchanged frame by frame on a second stream while the next group renders (ShardedScene.render_frames)
+    grouped_dist = use_dist and args.exchange == "rccl" and not args.no_overlap and args.submit == "frames"
+    sharded = None
+    if grouped_dist:
+        from tiny_renderer_amd.sharded import ShardedScene
+        sharded = ShardedScene(W, H, mesh, texs, pipe, device=device_index, frames_per_launch=args.frames_per_launch)
+    scene = sharded.scene if grouped_dist else T.Scene(W, H, mesh, texs, pipe, device=device_index,
                     stream=render_stream.cuda_stream if use_dist else None,
                     frame_buffer_device=fb_ptr[0] if use_dist else None, band_rows=band,
                     frames_per_launch=args.frames_per_launch,
                     trust_frame_buffers=use_dist)   # (the frame tensors are written by this scene and the exchange only)
-    frames_per_launch = scene.frames_per_launch if grouped else 1
+    frames_per_launch = scene.frames_per_launch if (grouped or grouped_dist) else 1
     chunks = None
     band_bytes = 0
     if use_dist:
@@ -236,6 +243,8 @@ def main():
             chunks = [fb[rank * band_bytes:(rank + 1) * band_bytes] for fb in fbs]
 
     def read_frame(b):
+        if grouped_dist:
+            return sharded.last_frame_tensor().cpu().numpy().reshape(H, W, 3)
         if not use_dist:
             return scene.get_frame_buffer()
         if exchange is not None:
@@ -259,6 +268,12 @@ def main():
             timing["timed"][b] = False
 
     def step(cam_now=cam):
+        if grouped_dist:
+            sharded.clear()
+            sharded.set_light_direction(lt)
+            sharded.set_camera(*cam_now)
+            sharded.render()
+            return
         if not use_dist:
             scene.clear()
             scene.set_light_direction(lt)
@@ -301,6 +316,9 @@ def main():
 
     def run(k, cams=None, per_frame=False):
         """k steps.  Grouped submission: ONE tr_scene_render_frames call for all of them."""
+        if grouped_dist and not per_frame:
+            sharded.render_frames(headline_params[:k] if cams is None else frame_params(cams))
+            return
         if grouped and not per_frame:
             scene.render_frames(headline_params[:k] if cams is None else frame_params(cams))
             return
@@ -322,6 +340,10 @@ def main():
         grown them by then).  Taken together: a rank that repeated a loop on its own would issue more
         collectives than its peers."""
         overflow = False
+        if grouped_dist:
+            # (collective, and repairs an overflow itself by rendering the last group again on every rank)
+            st = sharded.sync()
+            return True, st
         try:
             st = scene.sync()
         except T.TinyRendererError as e:
@@ -404,7 +426,7 @@ def main():
             step()
             if use_dist:
                 torch.cuda.synchronize()
-            scene.sync()
+            (sharded if grouped_dist else scene).sync()
             lat.append((time.perf_counter() - t1) * 1e6)
         lat.sort()
         latency_us = {"median": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1)}
@@ -576,7 +598,7 @@ def main():
             "config": {"workload": workload, "n_shaded_per_frame": n_shaded,
                        "polygons": int(mesh["idx"].shape[0]),
                        "submission": ("tr_scene_render_frames: %d frames per launch of each kernel, every frame into "
-                                      "render targets of its own" % frames_per_launch) if grouped
+                                      "render targets of its own" % frames_per_launch) if (grouped or grouped_dist)
                        else "per frame: clear, set_light_direction, set_camera, render",
                        "frames_per_launch": frames_per_launch,
                        "sharding": ("screen row bands (tr_band_rows) + %s of the framebuffer%s" % (
@@ -584,6 +606,9 @@ def main():
                            "" if args.no_overlap else ", double-buffered: exchange of frame f under the render of f+1"))
                        if use_dist else "none"},
             "group_ranks": group_ranks if use_dist else 1,
+            # what every rank ships per frame: its band to each of the others (dense: the sparse exchange is not built)
+            "exchange_bytes_per_frame": int(band_bytes * (world - 1)) if use_dist else 0,
+            "scaling_measured": "unmeasured here: one GPU per box (SCALE is the driver's 8-GPU run)" if world == 1 else "this run",
             "frames_per_s": round(args.steps / elapsed, 1),
             "frames_per_s_orbit": round(orbit_frames / orbit_elapsed, 1) if orbit_elapsed and orbit_status == 0 else None,
             "framebuffer_mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
@@ -614,8 +639,9 @@ def main():
         dist.barrier()
         if exchange is not None:
             exchange.close()
+    (sharded if grouped_dist else scene).close()
+    if use_dist:
         dist.destroy_process_group()
-    scene.close()
     if out is not None and not out["parity_vs_oracle"]["ok"]:
         raise SystemExit("GPU frame differs from the oracle")
 

@@ -231,6 +231,16 @@ class ShardedScene:
         t = self._last_tensor if self._last_tensor is not None else self._fbs[self._slot]
         return t.cpu().numpy().reshape(self.height, self.width, 3)
 
+    def last_frame_tensor(self):
+        """The frame tensor the newest frame is (being) exchanged into -- not collective: valid once a sync() of all
+        ranks has returned."""
+        return self._last_tensor if self._last_tensor is not None else self._fbs[self._slot]
+
+    @property
+    def scene(self):
+        """This rank's band scene (profiling, flush)."""
+        return self._scene
+
     def close(self):
         self._torch.cuda.synchronize()
         self._scene.close()
