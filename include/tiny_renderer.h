@@ -39,7 +39,10 @@ enum {
     TR_E_HIP = -6,              /* HIP runtime failure or no usable device */
     TR_E_IO = -7,               /* file missing / unreadable (app.rs:94,99: `?`) */
     TR_E_FORMAT = -8,           /* unsupported OBJ / TGA content */
-    TR_E_BIN_OVERFLOW = -9,     /* triangle-bin capacity exceeded; raise tr_options.bin_capacity */
+    TR_E_BIN_OVERFLOW = -9,     /* the (polygon, screen tile) pairs of one pass exceeded the record pool AND the frame
+                                   could not be rendered again behind the caller's back (see tr_scene_sync); the
+                                   pool has been grown: render the frame again, or size it with
+                                   tr_options.bin_capacity.  No single tile has a capacity. */
     TR_E_NOMEM = -10,
     TR_E_EXCHANGE = -11,        /* multi-GPU frame exchange: a peer's band did not arrive */
     TR_E_RCCL = -12             /* RCCL backend of the frame exchange: librccl missing or a collective failed */
@@ -85,8 +88,10 @@ typedef struct tr_options {
     void *stream;              /* hipStream_t to enqueue on; NULL = library-owned stream */
     void *frame_buffer_device; /* device pointer to 3*W*H bytes to render into (e.g. the
                                   all-gather buffer); NULL = library-owned */
-    uint64_t bin_capacity;     /* polygon records per screen-tile bin; 0 = default (256); bins grow
-                                  on overflow and the frame is rendered again */
+    uint64_t bin_capacity;     /* records in a pass's pool = (polygon, 128x16 screen tile) pairs of one pass of one
+                                  frame; every tile gets exactly the records it needs from it.  0 = automatic
+                                  (8 per polygon, at least 65 536).  A pass that needs more grows the pools and
+                                  the frame is rendered again. */
     uint32_t tile_waves;       /* wavefronts per 128x16 screen tile: 4, 8, 16, or 0 = automatic (more
                                   while the tiles cannot fill the GPU, 4 from 4096x4096 up).
                                   Speed only: results do not depend on it. */

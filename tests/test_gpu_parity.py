@@ -410,9 +410,10 @@ def test_baseline_configs_at_full_size(diablo, cfg):
 
 @pytest.mark.parametrize("pipe", ["phong", "shadow"])
 def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
-    """More polygons per tile than the bins hold: the library grows the bins and renders the
-    frame again, transparently for a frame that started from clear()."""
-    mesh, texs = synthetic  # 5 022 polygons on a 256x256 frame: hundreds per 128x32 tile
+    """More (polygon, tile) pairs in a pass than the record pool holds (a pool of 64, far below the automatic
+    size): the library grows the pools and renders the frame again, transparently for a frame that started
+    from clear()."""
+    mesh, texs = synthetic  # 5 022 polygons on a 256x256 frame: hundreds per 128x16 tile
     gpu, cpu = render_pair(256, 256, mesh, texs, pipe, 0.3, 0.2, bin_capacity=64)
     assert_parity(gpu, cpu, pipe)
     # and the grown bins serve the next frame directly
@@ -421,6 +422,42 @@ def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
         s.set_camera(*H.camera(1.3))
         s.render()
     assert_parity(gpu, cpu, pipe)
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow"])
+def test_many_polygons_in_one_tile_render_the_first_time(built, pipe):
+    """No tile has a capacity: every tile gets exactly the records its polygons need from the pass's pool
+    (k_setup counts, k_order places, k_bin fills).  A 20 088-polygon sphere shrunk to a dozen pixels in the middle
+    of a 512x512 frame -- the four 128x16 tiles that meet there get ten times the 256 records that used to be a
+    bin, each -- renders with the default options in ONE launch of each kernel per pass (a second tile-kernel
+    launch would be the frame rendered again after an overflow), bit-identical to the oracle."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = T.synthetic_scene(n_lat=62, n_lon=162, tex_size=256)
+    mesh = dict(mesh, pos=(mesh["pos"] * np.float32(0.04)).astype(np.float32))
+    W = Hh = 512
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True)
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    gpu.profile_enable(True)
+    for s_ in (gpu, cpu):
+        s_.clear()
+        s_.set_light_direction(H.light(0.2))
+        s_.set_camera(*H.camera(0.3))
+    assert cpu.render() == 0
+    gpu.render()
+    gpu.sync()
+    # how many polygons the busiest tile holds: winners alone show thousands of distinct polygons in a few tiles
+    win = cpu.winner_u32()
+    drawn = np.unique(win[win != 0xFFFFFFFF]).size
+    ys, xs = np.nonzero(win != 0xFFFFFFFF)
+    tiles = {(int(x) // 128, int(y) // 16) for x, y in zip(xs, ys)}
+    assert len(tiles) <= 6 and mesh["idx"].shape[0] // 2 // len(tiles) > 1500, (len(tiles), drawn)
+    prof = gpu.profile_read()
+    n_passes = 2 if pipe == "shadow" else 1
+    assert sum(v["launches"] for k, v in prof.items() if k.startswith("k_tile")) == n_passes, prof  # (the depth pass has its own entry)
+    assert prof["k_bin"]["launches"] == n_passes, prof
+    assert_parity(gpu, cpu, pipe)
+    gpu.close()
 
 
 def test_shadow_fetch_through_flags_on_the_device(built):

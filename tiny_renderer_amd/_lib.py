@@ -161,7 +161,12 @@ def load_library():
                                     "__graft_entry__.build()); there is no CPU fallback" % (_LIB, _CSRC))
         L = C.CDLL(_LIB)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("TR_LIBRARY"):   # an older build loaded for an A/B measurement: it lacks newer entry points
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

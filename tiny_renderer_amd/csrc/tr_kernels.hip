@@ -26,8 +26,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "tr_kernels.h"
@@ -49,165 +47,189 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 // -----------------------------------------------------------------------------------------
 // k_setup
 // -----------------------------------------------------------------------------------------
-constexpr uint32_t SETUP_POLYS = 64;  // polygons per 64-lane workgroup of k_setup, at most (launch_setup chooses)
-// what pair_masks needs of a polygon: clamped box and raster coordinates (40 bytes)
-struct SetupRaster {
-    int32_t bx0, bx1, by0, by1, x0, y0, x1, y1, x2, y2;
-};
-constexpr uint32_t SETUP_LDS_BUDGET = 9728;
-constexpr uint32_t setup_lds_bytes(uint32_t polys, uint32_t pieces) { return polys * (pieces * 16u + (uint32_t)sizeof(SetupRaster)) + 4u * 64u * 4u; }
+// Binning is EXACT: k_setup runs the vertex stage and counts, per tile, the polygons whose clamped box meets it;
+// k_order gives every tile with polygons a range of exactly that many records in the pass's pool (one atomic per
+// wave: tiles need no particular order in the pool); k_bin then fills the ranges.  No tile has a capacity: ten
+// times the usual number of polygons in one tile is just a longer range.  What is bounded is the pool -- the
+// pairs of the whole pass -- sized generously by the host and grown (the frame rendered again) should a pass ever
+// exceed it.  (Round 2 gave every tile a fixed-capacity bin: 4 GiB of reservations at 4096^2 for 2.6 MB of records
+// per frame, and TR_E_BIN_OVERFLOW whenever one tile saw more than its share.)
+// Workgroups of the chain's kernels are FOUR independent waves: a compute unit that is full of tile-kernel
+// workgroups admits a wave of another kernel only where a tile workgroup has left, and that wave -- on one SIMD --
+// then keeps the next tile workgroup (a wave on every SIMD) out for as long as it lives.  Four waves that arrive
+// together, one per SIMD, block that one slot once; as 64-thread workgroups the same waves blocked up to four
+// slots, and the 4096^2 tile kernel ran 4 % slower beside them.  (A lone frame's chain has the machine to itself
+// and is launched as single waves: they spread over four times as many compute units.)
+constexpr uint32_t CHAIN_WAVES = 4;
+constexpr uint32_t CHAIN_THREADS = 64 * CHAIN_WAVES;
 
 template <int VS>
-__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, uint32_t polys)
+__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
 {
     constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    // LDS, sized by the launch for `polys` polygons (setup_lds_bytes): records, raster coordinates for the pair
-    // masks, the binning's per-lane tables.  Kept under 10 KiB: that is what six resident workgroups of the tile
-    // kernel leave free on a compute unit, and a setup workgroup that does not fit beside them displaces one
-    // (11 KiB per workgroup cost the 4096^2 tile kernel 7 %).
-    extern __shared__ uint4 s_setup[];
-    uint4 *const s_rec = s_setup;
-    SetupRaster *const s_rast = reinterpret_cast<SetupRaster *>(s_setup + polys * P);
-    int32_t *const s_excl = reinterpret_cast<int32_t *>(s_rast + polys), *const s_tx0 = s_excl + 64, *const s_ty0 = s_tx0 + 64,
-                   *const s_ntx = s_ty0 + 64;
-
-    // Lane = polygon for the vertex stage (the first `polys` lanes: a small mesh is spread over more waves
-    // than it has sixty-fourths, because the wave with the most (polygon, tile) pairs is the kernel's
-    // critical path and a lone frame waits for it); all 64 lanes then share the binning below.
+    // Lane = polygon: vertex closure, truncating projection, clamped box; the polygon's record goes to the pass's
+    // record array ONCE (k_bin copies it to the tiles), its tiles' counters are bumped with atomics that return
+    // nothing, so nothing waits for them.
+    __builtin_amdgcn_s_setprio(3);  // (see k_order)
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = block * polys + lane;
-    // the 16 words behind this pass's counters (k_order's list lengths): their
-    // last readers -- the tile kernel of the pass that had the set before -- are done (the host orders that)
+    const uint32_t t = block * blockDim.x + lane;
+    // the 16 words behind this pass's counters (k_order's list lengths and pool cursor): their last readers --
+    // the tile kernel of the pass that had the set before -- are done (the host orders that)
     if (block == 0u && lane < 16u) a.tile_count[a.frame.ntx * a.frame.nty + lane] = 0u;
-
-    int32_t tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
+    if (t >= a.mesh.n_tri) return;
     uint32_t err = 0;
-    if (lane < polys && t < a.mesh.n_tri) {
-        RasterRec r;
-        float v[VARY_STRIDE];
+    RasterRec r;
+    float v[VARY_STRIDE];
 #pragma unroll
-        for (int i = 0; i < VARY_STRIDE; i++) v[i] = 0.0f;
-        const bool keep = vertex_stage<VS>(a.mesh, a.u, t, r, v, err);
-        if (keep)
-            finish_raster_rec(r, a.frame);
-        else
-            mark_rejected(r);
-        if (r.bx0 <= r.bx1) {
-            uint4 *o = s_rec + lane * P;
-            // piece 0: the clamped box (coordinates below 2^15) and, per tile, the pair's coverage masks
-            // (pair_masks, tr_shaders.h: filled in when the record is appended to a bin)
-            o[0] = make_uint4((uint32_t)r.bx0 | ((uint32_t)r.bx1 << 16), (uint32_t)r.by0 | ((uint32_t)r.by1 << 16), 0u, 0u);
-            // vertex 0 and the two edge vectors from it, the latter already as the f32 values every
-            // pixel's to_barycentric_coord starts from (scene.rs:178-181: integer difference, then
-            // the conversion) -- the tile kernel's shading phase used to redo these 8 subtractions
-            // and 8 conversions for every pixel pair
-            const Edge e = edge_setup(r);
-            o[1] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, __float_as_uint(e.a0), __float_as_uint(e.b0));
-            o[2] = make_uint4(__float_as_uint(e.a1), __float_as_uint(e.b1), __float_as_uint(r.z0), __float_as_uint(r.z1));
-            o[3] = make_uint4(__float_as_uint(r.z2), t, __float_as_uint(v[0]), __float_as_uint(v[1]));
+    for (int i = 0; i < VARY_STRIDE; i++) v[i] = 0.0f;
+    const bool keep = vertex_stage<VS>(a.mesh, a.u, t, r, v, err);
+    if (keep)
+        finish_raster_rec(r, a.frame);
+    else
+        mark_rejected(r);
+    uint4 *o = reinterpret_cast<uint4 *>(a.recs) + (size_t)t * P;
+    // piece 0: the clamped box (coordinates below 2^15; bx0 = 1 > bx1 = 0: draws nothing) and, in a tile's copy,
+    // the pair's coverage masks (pair_masks, tr_shaders.h: filled in by k_bin)
+    // (a polygon that draws nothing may have any coordinates: it gets the canonical empty box)
+    o[0] = r.bx0 <= r.bx1 ? make_uint4((uint32_t)r.bx0 | ((uint32_t)r.bx1 << 16), (uint32_t)r.by0 | ((uint32_t)r.by1 << 16), 0u, 0u)
+                          : make_uint4(1u, 0u, 0u, 0u);
+    if (r.bx0 <= r.bx1) {
+        // vertex 0 and the two edge vectors from it, the latter already as the f32 values every
+        // pixel's to_barycentric_coord starts from (scene.rs:178-181: integer difference, then
+        // the conversion) -- the tile kernel's shading phase used to redo these 8 subtractions
+        // and 8 conversions for every pixel pair
+        const Edge e = edge_setup(r);
+        o[1] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, __float_as_uint(e.a0), __float_as_uint(e.b0));
+        o[2] = make_uint4(__float_as_uint(e.a1), __float_as_uint(e.b1), __float_as_uint(r.z0), __float_as_uint(r.z1));
+        o[3] = make_uint4(__float_as_uint(r.z2), t, __float_as_uint(v[0]), __float_as_uint(v[1]));
 #pragma unroll
-            for (int i = 4; i < P; i++)
-                o[i] = make_uint4(__float_as_uint(v[4 * i - 14]), __float_as_uint(v[4 * i - 13]),
-                                  __float_as_uint(v[4 * i - 12]), __float_as_uint(v[4 * i - 11]));
-            // spare last word (varying 9 / 21 is unused): RN(1 / cross.z), the one IEEE division
-            // per polygon; k_tile derives every per-pixel quotient from it (tr_math.h div_by)
-            o[P - 1].w = __float_as_uint(record_recip(r));
-            SetupRaster sr;
-            sr.bx0 = r.bx0; sr.bx1 = r.bx1; sr.by0 = r.by0; sr.by1 = r.by1;
-            sr.x0 = r.x0; sr.y0 = r.y0; sr.x1 = r.x1; sr.y1 = r.y1; sr.x2 = r.x2; sr.y2 = r.y2;
-            s_rast[lane] = sr;
-            tx0 = r.bx0 / TILE_W;
-            ty0 = r.by0 / TILE_H;
-            ntx = r.bx1 / TILE_W - tx0 + 1;
-            cnt = ntx * (r.by1 / TILE_H - ty0 + 1);
-        }
+        for (int i = 4; i < P - 1; i++)
+            o[i] = make_uint4(__float_as_uint(v[4 * i - 14]), __float_as_uint(v[4 * i - 13]),
+                              __float_as_uint(v[4 * i - 12]), __float_as_uint(v[4 * i - 11]));
+        // spare last word (varying 9 / 21 is unused): RN(1 / cross.z), the one IEEE division
+        // per polygon; k_tile derives every per-pixel quotient from it (tr_math.h div_by)
+        o[P - 1] = make_uint4(__float_as_uint(v[4 * (P - 1) - 14]), __float_as_uint(v[4 * (P - 1) - 13]),
+                              __float_as_uint(v[4 * (P - 1) - 12]), __float_as_uint(record_recip(r)));
+        const int32_t tx0 = r.bx0 / TILE_W, tx1 = r.bx1 / TILE_W, ty0 = r.by0 / TILE_H, ty1 = r.by1 / TILE_H;
+        for (int32_t ty = ty0; ty <= ty1; ty++)
+            for (int32_t tx = tx0; tx <= tx1; tx++)
+                __hip_atomic_fetch_add(&a.tile_count[tile_index(a.frame, tx, ty)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (err) {
         atomicOr(a.err, err);
         *a.alarm = 1u;
     }
+}
 
-    // Binning.  One lane per polygon would serialise a polygon's atomics (a polygon spanning 30
-    // tiles = 30 dependent round trips); instead the wave's (polygon, tile) pairs are numbered by
-    // a prefix sum and dealt round-robin to the lanes, PAIRS per lane per trip so that their
-    // returning atomics are in flight together.
+template <int VS>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_setup(SetupArgs a)
+{
+    setup_body<VS>(a, blockIdx.x);
+}
+
+// k_bin: copies every polygon's record into the range of each tile its box meets, with the pair's coverage masks.
+// One lane per polygon would serialise a polygon's copies (a polygon spanning 30 tiles = 30 dependent round
+// trips); instead the wave's (polygon, tile) pairs are numbered by a prefix sum and dealt round-robin to the
+// lanes, PAIRS per lane per trip so that their returning atomics are in flight together.  A pair's place in the
+// pool comes from counting the tile's counter DOWN from the end of the tile's range (k_order left it there).
+// `polys`: polygons per wave (the wave with the most pairs is the kernel's critical path, and a lone frame waits
+// for it: few for a small mesh).
+constexpr uint32_t BIN_POLYS = 64;
+
+__device__ __forceinline__ uint4 shuffle_piece(const uint4 &v, int32_t from)
+{
+    return make_uint4((uint32_t)__shfl((int)v.x, from, 64), (uint32_t)__shfl((int)v.y, from, 64), (uint32_t)__shfl((int)v.z, from, 64),
+                      (uint32_t)__shfl((int)v.w, from, 64));
+}
+
+template <int P>
+__device__ __forceinline__ void bin_body(const SetupArgs &a, uint32_t block, uint32_t polys)
+{
+    __builtin_amdgcn_s_setprio(3);  // (see k_order)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t = (block * (blockDim.x >> 6) + (threadIdx.x >> 6)) * polys + lane;
+    int32_t corner = 0, ntx = 1, cnt = 0;  // corner: first tile column | first tile row << 16
+    // the lane's polygon, in registers: the lanes that copy it to a tile fetch it from here with shuffles (no LDS:
+    // nothing to fit beside the tile kernel's workgroups, no barrier)
+    uint4 mine[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) mine[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < polys && t < a.mesh.n_tri) {
+        const uint4 *const rec = reinterpret_cast<const uint4 *>(a.recs) + (size_t)t * P;
+#pragma unroll
+        for (int i = 0; i < P; i++) mine[i] = rec[i];  // (a polygon that draws nothing has only its box written: the rest is not used)
+        const int32_t bx0 = (int32_t)(mine[0].x & 0xFFFFu), bx1 = (int32_t)(mine[0].x >> 16);
+        const int32_t by0 = (int32_t)(mine[0].y & 0xFFFFu), by1 = (int32_t)(mine[0].y >> 16);
+        if (bx0 <= bx1) {
+            corner = bx0 / TILE_W | (by0 / TILE_H) << 16;
+            ntx = bx1 / TILE_W - bx0 / TILE_W + 1;
+            cnt = ntx * (by1 / TILE_H - by0 / TILE_H + 1);
+        }
+    }
     int32_t incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int32_t up = __shfl_up(incl, d, 64);
         if ((int)lane >= d) incl += up;
     }
-    const int32_t total = __shfl(incl, 63, 64);
-    s_excl[lane] = incl - cnt;
-    s_tx0[lane] = tx0;
-    s_ty0[lane] = ty0;
-    s_ntx[lane] = ntx;
-    __syncthreads();
+    const int32_t total = __shfl(incl, 63, 64), excl = incl - cnt;
 
-    constexpr int PAIRS = 8;  // pairs per lane per trip: their atomics are in flight together
-    for (int32_t p0 = (int32_t)lane; p0 < total; p0 += 64 * PAIRS) {
-        int32_t own[PAIRS], tile[PAIRS], ptx[PAIRS], pty[PAIRS];
-        uint32_t slot[PAIRS];
+    constexpr int PAIRS = 2;  // pairs per lane per trip: their atomics are in flight together
+    for (int32_t p0 = 0; p0 < total; p0 += 64 * PAIRS) {
+        int32_t own[PAIRS], origin[PAIRS];
+        uint32_t at[PAIRS];
+        bool have[PAIRS];
 #pragma unroll
         for (int k = 0; k < PAIRS; k++) {
-            const int32_t p = p0 + 64 * k;
-            own[k] = -1;
-            tile[k] = 0;
-            ptx[k] = pty[k] = 0;
-            if (p < total) {
-                // owner = last lane whose exclusive offset is <= p (lanes without pairs share
-                // their successor's offset, so "last" skips them)
-                int32_t lo = 0, hi = 63;
+            have[k] = false;
+            own[k] = 0;
+            if (p0 + 64 * k >= total) continue;  // (uniform)
+            const int32_t p = p0 + 64 * k + (int32_t)lane;
+            // owner = last lane whose exclusive offset is <= p (lanes without pairs share
+            // their successor's offset, so "last" skips them)
+            int32_t lo = 0, hi = 63;
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const int32_t mid = (lo + hi + 1) >> 1;
-                    if (s_excl[mid] <= p)
-                        lo = mid;
-                    else
-                        hi = mid - 1;
-                }
-                const int32_t q = p - s_excl[lo], w = s_ntx[lo];
-                own[k] = lo;
-                ptx[k] = s_tx0[lo] + q % w;
-                pty[k] = s_ty0[lo] + q / w;
-                tile[k] = tile_index(a.frame, ptx[k], pty[k]);
+            for (int i = 0; i < 6; i++) {
+                const int32_t mid = (lo + hi + 1) >> 1;
+                if (__shfl(excl, mid, 64) <= p)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const int32_t q = p - __shfl(excl, lo, 64), w = __shfl(ntx, lo, 64), c = __shfl(corner, lo, 64);
+            own[k] = lo;
+            have[k] = p < total;
+            if (have[k]) {
+                const int32_t ptx = (c & 0xFFFF) + q % w, pty = (c >> 16) + q / w;
+                origin[k] = ptx | pty << 16;
+                at[k] = atomicSub(&a.tile_count[tile_index(a.frame, ptx, pty)], 1u) - 1u;
             }
         }
 #pragma unroll
-        for (int k = 0; k < PAIRS; k++)
-            slot[k] = own[k] >= 0 ? atomicAdd(&a.tile_count[tile[k]], 1u) : 0u;
-
-#pragma unroll
         for (int k = 0; k < PAIRS; k++) {
-            if (own[k] < 0) continue;
-            if (slot[k] < a.bin_cap) {
-                uint4 *dst = reinterpret_cast<uint4 *>(a.bins) + ((size_t)tile[k] * a.bin_cap + slot[k]) * P;
-                const uint4 *src = s_rec + own[k] * P;
-                // which cells (small pair) or block columns (large pair) of the box inside THIS tile can hold
-                // a fragment: the tile kernel evaluates no edge function to find its work
-                uint4 head = src[0];
-                const SetupRaster sr = s_rast[own[k]];
-                RasterRec rr;
-                rr.bx0 = sr.bx0; rr.bx1 = sr.bx1; rr.by0 = sr.by0; rr.by1 = sr.by1;
-                rr.x0 = sr.x0; rr.y0 = sr.y0; rr.x1 = sr.x1; rr.y1 = sr.y1; rr.x2 = sr.x2; rr.y2 = sr.y2;
-                pair_masks(rr, ptx[k] * TILE_W, pty[k] * TILE_H, a.cells != 0u, head.z, head.w);
-                dst[0] = head;
+            if (p0 + 64 * k >= total) continue;  // (uniform: every lane takes part in the shuffles)
+            uint4 piece[P];
 #pragma unroll
-                for (int i = 1; i < P; i++) dst[i] = src[i];
-            } else {
-                atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
-                *a.alarm = 1u;
-                atomicMax(a.bin_need, slot[k] + 1u);
-                atomicMin(a.overflow_seq, a.pass_seq);
-            }
+            for (int i = 0; i < P; i++) piece[i] = shuffle_piece(mine[i], own[k]);
+            // (pool exhausted: k_order has raised DE_BIN_OVERFLOW, the host renders again)
+            if (!have[k] || at[k] >= a.pool_cap) continue;
+            uint4 *dst = reinterpret_cast<uint4 *>(a.bins) + (size_t)at[k] * P;
+            // which cells (small pair) or block columns (large pair) of the box inside THIS tile can hold
+            // a fragment: the tile kernel evaluates no edge function to find its work
+            pair_masks((int32_t)(piece[0].x & 0xFFFFu), (int32_t)(piece[0].x >> 16), (int32_t)(piece[0].y & 0xFFFFu),
+                       (int32_t)(piece[0].y >> 16), (int32_t)piece[1].x, (int32_t)piece[1].y, __uint_as_float(piece[1].z),
+                       __uint_as_float(piece[2].x), __uint_as_float(piece[1].w), __uint_as_float(piece[2].y),
+                       (origin[k] & 0xFFFF) * TILE_W, (origin[k] >> 16) * TILE_H, a.cells != 0u, piece[0].z, piece[0].w);
+#pragma unroll
+            for (int i = 0; i < P; i++) dst[i] = piece[i];
         }
     }
 }
 
-template <int VS>
-__global__ __launch_bounds__(64) void k_setup(SetupArgs a, uint32_t polys)
+template <int P>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_bin(SetupArgs a, uint32_t polys)
 {
-    setup_body<VS>(a, blockIdx.x, polys);
+    bin_body<P>(a, blockIdx.x, polys);
 }
 
 // Read-only argument tables of the fused launches: viewed in the constant address space, so that the loads
@@ -219,9 +241,15 @@ using constant_ptr = const __attribute__((address_space(4))) T *;
 // The same for a group of frames in one launch (tr_scene_render_frames): blockIdx.y = frame, whose
 // arguments are entry y of a table in device memory.
 template <int VS>
-__global__ __launch_bounds__(64) void k_setup_group(const SetupArgs *__restrict__ table, uint32_t polys)
+__global__ __launch_bounds__(CHAIN_THREADS) void k_setup_group(const SetupArgs *__restrict__ table)
 {
-    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x, polys);
+    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x);
+}
+
+template <int P>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_bin_group(const SetupArgs *__restrict__ table, uint32_t polys)
+{
+    bin_body<P>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x, polys);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -264,23 +292,27 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t n)
     return lg >= (uint32_t)(ORDER_BUCKETS - 2) ? 0u : (uint32_t)(ORDER_BUCKETS - 2) - lg;
 }
 
-// `group` != null: blockIdx.y = frame of a group, whose counters and work lists are in entry y of the tile
-// kernel's argument table.
-__global__ __launch_bounds__(ORDER_THREADS) void k_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles,
-                                                          uint32_t bits, const TileArgs *__restrict__ group)
+// `group` != null: blockIdx.y = frame of a group, whose counters, work lists and pool are in entry y of the tile
+// kernel's argument table; else `one` describes the pass.
+constexpr int ORDER_POOL = ORDER_BUCKETS;  // word behind the list lengths (per-frame sets) / in the set's words: the pool cursor
+
+__global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t n_tiles, uint32_t bits, const TileArgs *__restrict__ group)
 {
-    uint32_t *lengths = tile_count + n_tiles;
-    if (group) {
-        tile_count = group[blockIdx.y].tile_count;
-        order = const_cast<WorkItem *>(group[blockIdx.y].order);
-        lengths = const_cast<uint32_t *>(group[blockIdx.y].list_len);  // (zeroed by the host with the table)
-    }
+    // The chain in front of a tile kernel is a few hundred waves that share their SIMDs with six tile-kernel waves
+    // each -- at equal priority every instruction of theirs waits its turn behind six others, and the NEXT pass's
+    // tile kernel waits for them.  They are raised: the tile kernel hardly notices a few hundred short waves.
+    __builtin_amdgcn_s_setprio(3);
+    const TileArgs &a = group ? group[blockIdx.y] : one;
+    uint32_t *const tile_count = a.tile_count;
+    WorkItem *const order = const_cast<WorkItem *>(a.order);
+    // (a fused launch's list lengths live in its table entry, zeroed by the host with the table)
+    uint32_t *const lengths = group ? const_cast<uint32_t *>(group[blockIdx.y].list_len) : tile_count + n_tiles;
+    uint32_t *const pool_cursor = tile_count + n_tiles + ORDER_POOL;
     const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const bool live = i < n_tiles;
     const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
     const uint32_t n = live ? tile_count[t] : 0u;
-    if (live && n != 0u) tile_count[t] = 0u;
     const uint32_t bk = order_bucket(n);
     uint32_t mine = 0u, rank = 0u;
 #pragma unroll
@@ -289,14 +321,53 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order(uint32_t *tile_count, W
         if (lane == (uint32_t)b) mine = (uint32_t)__builtin_popcountll(m);
         if (bk == (uint32_t)b) rank = (uint32_t)__builtin_popcountll(m & below);
     }
-    uint32_t base = 0u;
+    // the wave's tiles take one contiguous piece of the pool: running sum over the lanes, the waves' sums over
+    // the workgroup, ONE atomic per workgroup (every tile of every frame of a group passes through this one
+    // word, and a single address takes ~90 atomics per microsecond)
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
+    __shared__ uint32_t s_total[ORDER_THREADS / 64], s_base;
+    if (lane == 0u) s_total[threadIdx.x >> 6] = wave_total;
+    __syncthreads();
+    uint32_t block_total = 0u, before = 0u;
+#pragma unroll
+    for (int w = 0; w < ORDER_THREADS / 64; w++) {
+        if ((uint32_t)w < (threadIdx.x >> 6)) before += s_total[w];
+        block_total += s_total[w];
+    }
+    // (the list atomics and the pool atomic are in flight together)
+    uint32_t base = 0u, pool_base = 0u;
     if (lane < (uint32_t)ORDER_BUCKETS && mine) base = atomicAdd(&lengths[lane], mine);
+    if (threadIdx.x == 0u && block_total) pool_base = atomicAdd(pool_cursor, block_total);
+    if (threadIdx.x == 0u) s_base = pool_base;
     const uint32_t pos = (uint32_t)__shfl((int)base, (int)bk, 64) + rank;
+    __syncthreads();
+    const uint32_t wave_base = s_base + before;
+    const uint32_t offset = wave_base + (incl - n);
+    if (lane == 0u && wave_total && (uint64_t)wave_base + wave_total > a.pool_cap) {
+        // the pass wants more records than the pool holds: the frame is truncated, the host grows the pools to at
+        // least what has been asked for so far and renders again
+        atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
+        *a.alarm = 1u;
+        atomicMax(a.bin_need, wave_base + wave_total);
+        atomicMin(a.overflow_seq, a.pass_seq);
+    }
     if (live) {
         WorkItem w;
         w.tile = t;
-        w.count = n;
+        // a tile whose range leaves the pool: what fits (k_bin writes no further)
+        w.count = offset >= a.pool_cap ? 0u : min(n, a.pool_cap - offset);
+        w.offset = offset;
+        w.pad = 0u;
         order[(size_t)bk * n_tiles + pos] = w;
+        // k_bin counts the tile's counter down from the END of its range: what an atomic returns is the record's
+        // place in the pool; the tile kernel's workgroup for the tile zeroes the counter for the set's next pass
+        if (n) tile_count[t] = offset + n;
     }
 }
 
@@ -517,6 +588,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const WorkItem work = a.order[(size_t)list * n_tiles + entry];
     const uint32_t tile = work.tile;
     uint32_t n = work.count;
+    // (k_bin has counted the tile's counter down to the start of its range; the set's next pass counts from zero)
+    if (tid == 0u && list != (uint32_t)ORDER_EMPTY) a.tile_count[tile] = 0u;
     if (n == 0u) {
         if (a.fresh) {
             // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
@@ -536,7 +609,6 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         }
         return;
     }
-    if (n > a.bin_cap) n = a.bin_cap;  // overflow: flagged by k_setup, the host renders again
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
     const int32_t tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
@@ -559,9 +631,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     // sharing deals whole polygons to waves, and four polygons that each cross the entire tile would
     // occupy four waves for 16 column pairs each while the others idle (2048^2: such tiles were the
     // slowest of the frame, 19-21 us); columns split exactly that work evenly.
-    const bool shared_tile = SHARED && n >= 2u * (uint32_t)TILE_WAVES;
+    const bool shared_tile = SHARED && n >= 2u * (uint32_t)TILE_WAVES && n <= SHARED_MAX_SLOTS;  // (the key's slot field)
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
-    const uint4 *bin = reinterpret_cast<const uint4 *>(a.bins) + (size_t)tile * a.bin_cap * P;
+    const uint4 *bin = reinterpret_cast<const uint4 *>(a.bins) + (size_t)work.offset * P;  // the tile's records in the pool
     const bool resident = n <= (uint32_t)NMAX;  // the whole bin stays in LDS through shading
 
     // ---- initial keys, coverage + depth resolve: one body for both forms ------------------------
@@ -1382,23 +1454,15 @@ int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_
 {
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
-    // polygons per wave: all 64 lanes when that still gives the machine a few hundred waves (the x64 grid's 321 408
-    // polygons; 32 for a group of four frames of 5 022), fewer for a lone frame of a small mesh, which waits for the
-    // slowest wave (8: 628 waves); never more than the LDS budget holds
-    uint32_t polys = SETUP_POLYS;
-    while (polys > 8u && ((uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 512u ||
-                          setup_lds_bytes(polys, a.rec_pieces) > SETUP_LDS_BUDGET))
-        polys >>= 1;
-    static const int forced = getenv("TR_SETUP_POLYS") ? atoi(getenv("TR_SETUP_POLYS")) : 0;  // experiment hook
-    if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && setup_lds_bytes((uint32_t)forced, a.rec_pieces) <= 16384u) polys = (uint32_t)forced;
-    const uint32_t lds = setup_lds_bytes(polys, a.rec_pieces);
-    const dim3 grid(a.mesh.n_tri ? (a.mesh.n_tri + polys - 1u) / polys : 1u, group ? n_frames : 1u), block(64);  // (an empty mesh: its first workgroup still zeroes the pass's list words)
-#define TR_SETUP_CASE(V)                                                                              \
-    case V:                                                                                           \
-        if (group)                                                                                    \
-            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, lds, st, start, done, 0, group, polys);       \
-        else                                                                                          \
-            hipExtLaunchKernelGGL(k_setup<V>, grid, block, lds, st, start, done, 0, a, polys);                 \
+    // (an empty mesh: the first workgroup still zeroes the pass's list words)
+    const uint32_t threads = group ? CHAIN_THREADS : 64u;
+    const dim3 grid(a.mesh.n_tri ? (a.mesh.n_tri + threads - 1u) / threads : 1u, group ? n_frames : 1u), block(threads);
+#define TR_SETUP_CASE(V)                                                                   \
+    case V:                                                                                \
+        if (group)                                                                         \
+            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group); \
+        else                                                                               \
+            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a);      \
         break;
     switch (vs) {
     TR_SETUP_CASE(VS_DEFAULT)
@@ -1413,15 +1477,44 @@ int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_
     return 0;
 }
 
-int launch_order(uint32_t *tile_count, WorkItem *order, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames,
-                 hipStream_t st, hipEvent_t start, hipEvent_t done)
+int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done)
+{
+    if (a.mesh.n_tri == 0) return 0;
+    if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
+    // polygons per wave: all 64 lanes in a fused launch (throughput: the fewer waves, the less the tile kernel of
+    // the group in front is disturbed); for a lone frame, which WAITS for the wave with the most (polygon, tile)
+    // pairs, 8 when the mesh is small (628 waves for 5 022 polygons)
+    uint32_t polys = BIN_POLYS;
+    if (!group && (a.mesh.n_tri + polys - 1u) / polys < 512u) polys = 8u;
+    const uint32_t lds = 0u, waves = (a.mesh.n_tri + polys - 1u) / polys;
+    const uint32_t per_group = group ? CHAIN_WAVES : 1u;
+    const dim3 grid((waves + per_group - 1u) / per_group, group ? n_frames : 1u), block(64u * per_group);
+    if (a.rec_pieces == (uint32_t)REC_PIECES_LARGE) {
+        if (group)
+            hipExtLaunchKernelGGL(k_bin_group<REC_PIECES_LARGE>, grid, block, lds, st, start, done, 0, group, polys);
+        else
+            hipExtLaunchKernelGGL(k_bin<REC_PIECES_LARGE>, grid, block, lds, st, start, done, 0, a, polys);
+    } else if (a.rec_pieces == (uint32_t)REC_PIECES_SMALL) {
+        if (group)
+            hipExtLaunchKernelGGL(k_bin_group<REC_PIECES_SMALL>, grid, block, lds, st, start, done, 0, group, polys);
+        else
+            hipExtLaunchKernelGGL(k_bin<REC_PIECES_SMALL>, grid, block, lds, st, start, done, 0, a, polys);
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_order(const TileArgs &one, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start,
+                 hipEvent_t done)
 {
     if (n_tiles == 0) return 0;
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
     const dim3 grid((n_tiles + ORDER_THREADS - 1u) / ORDER_THREADS, group ? n_frames : 1u), block(ORDER_THREADS);
     uint32_t bits = 1;
     while ((1u << bits) < n_tiles) bits++;
-    hipExtLaunchKernelGGL(k_order, grid, block, 0, st, start, done, 0, tile_count, order, n_tiles, bits, group);
+    hipExtLaunchKernelGGL(k_order, grid, block, 0, st, start, done, 0, one, n_tiles, bits, group);
     TR_LAUNCH_CHECK();
     return 0;
 }
@@ -1462,7 +1555,7 @@ int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t 
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || (uint64_t)n_tiles * n_frames > 0x7FFFFFFFull)) return (int)hipErrorInvalidValue;
     // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns
-    if (n_polygons > SHARED_MAX_POLYGONS || a.bin_cap > SHARED_MAX_SLOTS) shared = 0;
+    if (n_polygons > SHARED_MAX_POLYGONS) shared = 0;  // (a tile with more records than the slot field holds resolves by columns: k_tile)
     if (shared) {
         if (tile_waves == 16) return launch_tile_waves<16, true>(fs, a, n_tiles, group, n_frames, st, start, done);
         if (tile_waves == 8) return launch_tile_waves<8, true>(fs, a, n_tiles, group, n_frames, st, start, done);

@@ -83,8 +83,8 @@ const PipelineDesc kPipelines[P_COUNT] = {
     { "occlusion", 2, { { 1, VS_DEPTH, FS_DEPTH }, { 2, VS_PLAIN, FS_OCCLUSION2 } } },
 };
 
-const char *kKernelNames[] = { "k_setup", "k_tile", "k_tile_depth", "k_clear", "k_order" };
-enum KernelId { K_SETUP = 0, K_TILE, K_TILE_DEPTH, K_CLEAR, K_ORDER, K_COUNT };
+const char *kKernelNames[] = { "k_setup", "k_tile", "k_tile_depth", "k_clear", "k_order", "k_bin" };
+enum KernelId { K_SETUP = 0, K_TILE, K_TILE_DEPTH, K_CLEAR, K_ORDER, K_BIN, K_COUNT };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -171,7 +171,8 @@ struct tr_scene {
     // Record bins and work lists, LOOKAHEAD-buffered by global pass number: pass p's setup fills
     // bins[p % LOOKAHEAD] while the tile kernels of the passes before it may still be reading theirs.
     WorkItem *d_order[LOOKAHEAD] = {};  // the tile kernel's work list (k_order)
-    Piece *d_bins[LOOKAHEAD] = {};      // each n_tiles_full x bin_cap records of rec_pieces x 16 B
+    Piece *d_bins[LOOKAHEAD] = {};      // the passes' pools: pool_cap records of rec_pieces x 16 B each
+    Piece *d_recs[LOOKAHEAD] = {};      // every polygon's record, once per pass (k_setup -> k_bin)
     // Pass pipelining: k_setup and k_order_* of pass p run on `setup_stream`, ordered after the tile
     // kernel of pass p - LOOKAHEAD (which freed its bins and zeroed its counters) and before the tile
     // kernel of pass p on the main stream.  They need only frame constants, so they overlap the tile
@@ -190,7 +191,7 @@ struct tr_scene {
     uint64_t last_submitted_seq = 0;   // pass number of the newest of them (its ev_tile tells whether the stream is idle)
     uint32_t tile_waves = 0;     // tr_options.tile_waves: 4, 8, 16 or 0 = by tile count
     uint32_t tile_mode = 0;      // tr_options.tile_mode: 1 columns, 2 shared bin, 0 = automatic
-    uint32_t bin_cap = 0;        // records per tile; grown on overflow
+    uint32_t pool_cap = 0;       // records in a pass's pool (all its (polygon, tile) pairs); grown should a pass exceed it
     uint32_t rec_pieces = 0;
     uint32_t *d_bin_need = nullptr;
     // First pass (global pass number) whose bins overflowed since the last sync, written by k_setup
@@ -223,13 +224,14 @@ struct tr_scene {
     uint32_t frames_per_launch = 0;  // tr_options.frames_per_launch; 0 = by tile count
     // One group in flight: bins, counters, work lists and argument tables of its frames' passes
     struct GroupSet {
-        Piece *bins = nullptr;      // [pass][frame] x bin tiles x bin_cap records
+        Piece *bins = nullptr;      // [pass][frame] x pool_cap records
+        Piece *recs = nullptr;      // [pass][frame] x polygons
         uint32_t *count = nullptr;  // [pass][frame] x (n_tiles_full + 16)
         WorkItem *order = nullptr;  // [pass][frame] x n_tiles_full
         uint8_t *d_tables = nullptr, *h_tables = nullptr;  // [pass] x frames SetupArgs, then [pass] x frames TileArgs
         hipEvent_t ev_setup = nullptr, ev_tile = nullptr;
         bool in_flight = false;
-        uint32_t bin_cap = 0, frames = 0;  // what the set was allocated for
+        uint32_t pool_cap = 0, frames = 0;  // what the set was allocated for
         uint32_t g = 0;                    // frames of the group it holds now
         int tile_waves[2] = { 4, 4 }, shared[2] = { 0, 0 };  // the tile kernels' layout, per pass (decided with the setup)
         bool chain_on_main = false;        // its setup was queued on the main stream itself (nothing was in flight)
@@ -619,7 +621,6 @@ int replay_tail(tr_scene *s);
 
 // Tiles the bins must cover: a band scene's colour passes touch its own rows only; the depth passes of
 // shadow / occlusion fill the whole shadow buffer on every rank (shader.rs:774-778).
-uint32_t bin_tiles(const tr_scene *s) { return kPipelines[s->pipeline].n_passes == 2 ? s->n_tiles_full : s->n_tiles; }
 
 // How the waves of a tile divide the work when tr_options.tile_mode leaves it open (speed only).
 int tile_mode_auto(int by_tile_count)
@@ -644,23 +645,22 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     HIP_TRY(hipMemcpy(&need, s->d_bin_need, sizeof need, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_bin_need, 0, sizeof need));
     HIP_TRY(hipStreamSynchronize(nullptr));  // (the scene's streams do not wait for the null stream)
-    uint64_t cap = s->bin_cap;
-    while (cap < need) cap *= 2;
-    if (cap > s->mesh.n_tri) cap = s->mesh.n_tri;
-    if (cap < need) cap = need;
+    uint64_t cap = s->pool_cap;
+    while (cap < need) cap *= 2;   // (need = the pairs the hungriest pass wanted)
+    if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
     {
         // per-frame sets + the frame groups' sets, if they exist
         uint64_t sets = LOOKAHEAD;
         for (const tr_scene::GroupSet &g : s->grp) sets += (uint64_t)g.frames * (uint64_t)kPipelines[s->pipeline].n_passes;
-        if (sets * cap * (uint64_t)bin_tiles(s) * s->rec_pieces * 16ull > (128ull << 30))
-            return tr::fail(TR_E_BIN_OVERFLOW, "triangle bins would exceed 128 GiB");
+        if (cap < need || sets * cap * s->rec_pieces * 16ull > (128ull << 30))
+            return tr::fail(TR_E_BIN_OVERFLOW, "the pools of polygon records would exceed 128 GiB");
     }
     HIP_TRY(hipStreamSynchronize(s->setup_stream));
-    s->bin_cap = (uint32_t)cap;
+    s->pool_cap = (uint32_t)cap;
     int st = TR_OK;
     for (int k = 0; k < LOOKAHEAD && st == TR_OK; k++) {
         dev_free(s->d_bins[k]);
-        st = dev_alloc(&s->d_bins[k], (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces);
+        st = dev_alloc(&s->d_bins[k], (size_t)s->pool_cap * s->rec_pieces);
     }
     if (st != TR_OK) return st;
     // (the frame groups' bins follow bin_cap when their set is next used)
@@ -669,15 +669,15 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
         snprintf(buf, sizeof buf,
                  "triangle bins overflowed in a frame that went to a caller's buffer and cannot be rendered again (an older "
                  "frame of tr_scene_render_frames, or of a fused group of per-frame renders): that buffer holds a truncated "
-                 "frame; the bins have been grown to %u records per tile: render it again", s->bin_cap);
+                 "frame; the pools have been grown to %u records per pass: render it again", s->pool_cap);
         return tr::fail(TR_E_BIN_OVERFLOW, buf);
     }
     if (first_bad_seq < s->observed_seq) {
         char buf[320];
         snprintf(buf, sizeof buf,
                  "triangle bins overflowed in a frame that was already handed on (asynchronous read-back or caller's "
-                 "stream): that frame is truncated; the bins have been grown to %u records per tile (a tile asked for %u, "
-                 "pass %llu of %llu): render it again", s->bin_cap, need, first_bad_seq, (unsigned long long)s->pass_seq);
+                 "stream): that frame is truncated; the pools have been grown to %u records per pass (a pass wanted %u, "
+                 "pass %llu of %llu): render it again", s->pool_cap, need, first_bad_seq, (unsigned long long)s->pass_seq);
         return tr::fail(TR_E_BIN_OVERFLOW, buf);
     }
     if (s->last_was_group) return replay_tail(s);  // frames older than the tail no longer exist anywhere
@@ -813,7 +813,7 @@ void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, uint32_t tiles_per
     shared = s->tile_mode ? (s->tile_mode == 2 ? 1 : 0) : tile_mode_auto((tiles_per_frame <= 2048u || dense) ? 1 : 0);
     // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns.  Decided
     // HERE, once per pass: k_setup prepares the pairs' masks for the form the tile kernel will run (SetupArgs::cells)
-    if (s->mesh.n_tri > (1u << 20) || s->bin_cap > 4093u) shared = 0;
+    if (s->mesh.n_tri > (1u << 20)) shared = 0;  // (a TILE with more records than the slot field holds resolves by columns: k_tile)
 }
 
 int run_pass(tr_scene *s, const PassDesc &p)
@@ -859,49 +859,21 @@ int run_pass(tr_scene *s, const PassDesc &p)
     const uint64_t p_seq = s->pass_seq;
     Piece *bins = s->d_bins[p_seq % LOOKAHEAD];
     sa.tile_count = bs.count[set_cur];
+    sa.recs = s->d_recs[p_seq % LOOKAHEAD];
     sa.bins = bins;
-    sa.bin_cap = s->bin_cap;
+    sa.pool_cap = s->pool_cap;
     sa.rec_pieces = s->rec_pieces;
-    sa.bin_need = s->d_bin_need;
     sa.err = s->d_err;
     sa.alarm = s->d_alarm;
-    sa.overflow_seq = s->d_overflow_seq;
-    sa.pass_seq = p_seq;
-    // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p.
-    // With NOTHING in flight (a frame rendered and read, rendered and read: the interactive loop) the chain has
-    // nothing to overlap with, and the hop between the streams -- event, wait packet, dispatch: 13-17 us -- is
-    // pure latency: then setup, work list and tiles go down the main stream in order.
-    // "Nothing in flight" is what the host KNOWS after it has waited for the stream (a loop that merely runs
-    // ahead of a fast GPU must keep its overlap: asking the stream instead cost small frames 7-16 %).
-    const bool chain_on_main = s->own_stream && s->quiescent && s->pending.empty() && s->group_submitted == s->group_seq;
-    s->quiescent = false;
-    hipStream_t chain = chain_on_main ? s->stream : s->setup_stream;
-    if (!chain_on_main && p_seq >= (uint64_t)LOOKAHEAD)
-        HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
-    if (!s->profiling) {
-        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, nullptr, nullptr);
-        if (rc) return launch_status(rc, "k_setup");
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, chain, nullptr,
-                          s->ev_setup[p_seq % RING]);
-        if (rc) return launch_status(rc, "k_order");
-    } else {
-        // profiling: timing events on the dispatches themselves, then the pipeline's event separately
-        EventPair ep = { take_event(s), take_event(s), K_SETUP, 1u };
-        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, ep.a, ep.b);
-        if (rc) return launch_status(rc, "k_setup");
-        if (s->mesh.n_tri) s->events.push_back(ep);
-        EventPair eo = { take_event(s), take_event(s), K_ORDER, 1u };
-        rc = launch_order(bs.count[set_cur], s->d_order[p_seq % LOOKAHEAD], n_tiles_pass, nullptr, 0, chain, eo.a, eo.b);
-        if (rc) return launch_status(rc, "k_order");
-        s->events.push_back(eo);
-        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], chain));
-    }
     TileArgs ta;
     ta.bins = bins;
-    ta.bin_cap = s->bin_cap;
+    ta.pool_cap = s->pool_cap;
     ta.rec_pieces = s->rec_pieces;
     ta.order = s->d_order[p_seq % LOOKAHEAD];
     ta.tile_count = bs.count[set_cur];
+    ta.bin_need = s->d_bin_need;
+    ta.overflow_seq = s->d_overflow_seq;
+    ta.pass_seq = p_seq;
     ta.frame = frame;
     ta.u = du;
     ta.tex = s->tex;
@@ -918,6 +890,43 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     ta.stamps = depth_pass ? nullptr : s->d_stamps;
+    // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p.
+    // With NOTHING in flight (a frame rendered and read, rendered and read: the interactive loop) the chain has
+    // nothing to overlap with, and the hop between the streams -- event, wait packet, dispatch: 13-17 us -- is
+    // pure latency: then setup, work list and tiles go down the main stream in order.
+    // "Nothing in flight" is what the host KNOWS after it has waited for the stream (a loop that merely runs
+    // ahead of a fast GPU must keep its overlap: asking the stream instead cost small frames 7-16 %).
+    const bool chain_on_main = s->own_stream && s->quiescent && s->pending.empty() && s->group_submitted == s->group_seq;
+    s->quiescent = false;
+    hipStream_t chain = chain_on_main ? s->stream : s->setup_stream;
+    if (!chain_on_main && p_seq >= (uint64_t)LOOKAHEAD)
+        HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
+    // the chain: vertex stage + counting, work lists + pool ranges, records into the ranges
+    if (!s->profiling) {
+        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, nullptr, nullptr);
+        if (rc) return launch_status(rc, "k_setup");
+        rc = launch_order(ta, n_tiles_pass, nullptr, 0, chain, nullptr, s->mesh.n_tri ? nullptr : s->ev_setup[p_seq % RING]);
+        if (rc) return launch_status(rc, "k_order");
+        rc = launch_bin(sa, nullptr, 0, chain, nullptr, s->ev_setup[p_seq % RING]);
+        if (rc) return launch_status(rc, "k_bin");
+    } else {
+        // profiling: timing events on the dispatches themselves, then the pipeline's event separately
+        EventPair ep = { take_event(s), take_event(s), K_SETUP, 1u };
+        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, ep.a, ep.b);
+        if (rc) return launch_status(rc, "k_setup");
+        s->events.push_back(ep);
+        EventPair eo = { take_event(s), take_event(s), K_ORDER, 1u };
+        rc = launch_order(ta, n_tiles_pass, nullptr, 0, chain, eo.a, eo.b);
+        if (rc) return launch_status(rc, "k_order");
+        s->events.push_back(eo);
+        if (s->mesh.n_tri) {
+            EventPair eb = { take_event(s), take_event(s), K_BIN, 1u };
+            rc = launch_bin(sa, nullptr, 0, chain, eb.a, eb.b);
+            if (rc) return launch_status(rc, "k_bin");
+            s->events.push_back(eb);
+        }
+        HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], chain));
+    }
     pt.fs = p.fs;
     pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
     pt.p_seq = p_seq;
@@ -986,7 +995,7 @@ uint32_t group_size(const tr_scene *s)
     uint32_t g = s->n_tiles ? 32768u / s->n_tiles : (uint32_t)GROUP_MAX;
     g = g < 4u ? 4u : g > (uint32_t)GROUP_MAX ? (uint32_t)GROUP_MAX : g;
     // the sets of bins of the groups in flight stay below 48 GiB (a 16384^2 frame: 3 GiB of bins per pass)
-    const uint64_t per_frame = (uint64_t)bin_tiles(s) * s->bin_cap * s->rec_pieces * 16ull * (uint64_t)kPipelines[s->pipeline].n_passes;
+    const uint64_t per_frame = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * (uint64_t)kPipelines[s->pipeline].n_passes;
     while (g > 1u && (uint64_t)GROUP_SETS * g * per_frame > (48ull << 30)) g--;
     return g;
 }
@@ -1018,7 +1027,8 @@ int ensure_slots(tr_scene *s, uint32_t n)
     return TR_OK;
 }
 
-size_t group_bins_per_frame(const tr_scene *s) { return (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces; }
+size_t group_bins_per_frame(const tr_scene *s) { return (size_t)s->pool_cap * s->rec_pieces; }
+size_t group_recs_per_frame(const tr_scene *s) { return (size_t)(s->mesh.n_tri ? s->mesh.n_tri : 1u) * s->rec_pieces; }
 size_t group_counts_per_frame(const tr_scene *s) { return (size_t)s->n_tiles_full + 16u; }
 
 int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
@@ -1029,18 +1039,19 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
         HIP_TRY(hipEventCreateWithFlags(&gs.ev_tile, hipEventDisableTiming));
     }
     int st = TR_OK;
-    if ((gs.frames < frames || gs.bin_cap != s->bin_cap) && gs.in_flight) {
+    if ((gs.frames < frames || gs.pool_cap != s->pool_cap) && gs.in_flight) {
         HIP_TRY(hipEventSynchronize(gs.ev_tile));  // its memory is about to be replaced
         gs.in_flight = false;
     }
     if (gs.frames < frames) {
         dev_free(gs.count);
         dev_free(gs.order);
+        dev_free(gs.recs);
         dev_free(gs.d_tables);
         if (gs.h_tables) (void)hipHostFree(gs.h_tables);
         gs.h_tables = nullptr;
         dev_free(gs.bins);
-        gs.bin_cap = 0;
+        gs.pool_cap = 0;
         gs.frames = 0;
         const size_t nc = np * frames * group_counts_per_frame(s);
         if ((st = dev_alloc(&gs.count, nc))) return st;
@@ -1051,16 +1062,17 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
         HIP_TRY(hipMemset(gs.count, 0, nc * 4));
         HIP_TRY(hipStreamSynchronize(nullptr));
         if ((st = dev_alloc(&gs.order, np * frames * (size_t)s->n_tiles_full * ORDER_LISTS))) return st;
+        if ((st = dev_alloc(&gs.recs, np * frames * group_recs_per_frame(s)))) return st;
         const size_t tb = np * frames * (sizeof(SetupArgs) + sizeof(TileArgs));
         if ((st = dev_alloc(&gs.d_tables, tb))) return st;
         HIP_TRY(hipHostMalloc((void **)&gs.h_tables, tb, hipHostMallocDefault));
         gs.frames = frames;
     }
-    if (gs.bin_cap != s->bin_cap) {
+    if (gs.pool_cap != s->pool_cap) {
         dev_free(gs.bins);
-        gs.bin_cap = 0;
+        gs.pool_cap = 0;
         if ((st = dev_alloc(&gs.bins, np * gs.frames * group_bins_per_frame(s)))) return st;
-        gs.bin_cap = s->bin_cap;
+        gs.pool_cap = s->pool_cap;
     }
     return TR_OK;
 }
@@ -1128,20 +1140,21 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             sa.mesh = s->mesh;
             sa.frame = frame;
             sa.tile_count = gs.count + e * group_counts_per_frame(s);
+            sa.recs = gs.recs + e * group_recs_per_frame(s);
             sa.bins = gs.bins + e * group_bins_per_frame(s);
-            sa.bin_cap = s->bin_cap;
+            sa.pool_cap = s->pool_cap;
             sa.rec_pieces = s->rec_pieces;
-            sa.bin_need = s->d_bin_need;
             sa.err = s->d_err;
             sa.alarm = s->d_alarm;
-            sa.overflow_seq = s->d_overflow_seq;
-            sa.pass_seq = s->pass_seq + (uint64_t)j * np + pi;  // frame by frame, as the per-frame path numbers them
             sa.cells = gs.shared[pi] ? 1u : 0u;
             ta.bins = sa.bins;
-            ta.bin_cap = s->bin_cap;
+            ta.pool_cap = s->pool_cap;
             ta.rec_pieces = s->rec_pieces;
             ta.order = gs.order + e * (size_t)s->n_tiles_full * ORDER_LISTS;
             ta.tile_count = sa.tile_count;
+            ta.bin_need = s->d_bin_need;
+            ta.overflow_seq = s->d_overflow_seq;
+            ta.pass_seq = s->pass_seq + (uint64_t)j * np + pi;  // frame by frame, as the per-frame path numbers them
             ta.frame = frame;
             ta.u = sa.u;
             ta.tex = s->tex;
@@ -1171,18 +1184,23 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
         const PassDesc &pass = pd.pass[pi];
         const SetupArgs &sa0 = h_setup[(size_t)pi * G];
         const uint32_t n_tiles_pass = sa0.frame.ntx * sa0.frame.nty;
-        EventPair ep = { nullptr, nullptr, K_SETUP, g }, eo = { nullptr, nullptr, K_ORDER, g };
+        EventPair ep = { nullptr, nullptr, K_SETUP, g }, eo = { nullptr, nullptr, K_ORDER, g }, eb = { nullptr, nullptr, K_BIN, g };
         if (s->profiling) {
             ep.a = take_event(s); ep.b = take_event(s);
             eo.a = take_event(s); eo.b = take_event(s);
+            eb.a = take_event(s); eb.b = take_event(s);
         }
         int rc = launch_setup(pass.vs, sa0, d_setup + (size_t)pi * G, g, chain, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
-        rc = launch_order(nullptr, nullptr, n_tiles_pass, d_tile + (size_t)pi * G, g, chain, eo.a, eo.b);
+        rc = launch_order(h_tile[(size_t)pi * G], n_tiles_pass, d_tile + (size_t)pi * G, g, chain, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
+        rc = launch_bin(sa0, d_setup + (size_t)pi * G, g, chain, eb.a, eb.b);
+        if (rc) return launch_status(rc, "k_bin");
         if (s->profiling) {
-            if (s->mesh.n_tri) s->events.push_back(ep);
+            s->events.push_back(ep);
             s->events.push_back(eo);
+            if (s->mesh.n_tri) s->events.push_back(eb);
+            else { s->event_pool.push_back(eb.a); s->event_pool.push_back(eb.b); }
         }
     }
     HIP_TRY(hipEventRecord(gs.ev_setup, chain));
@@ -1474,6 +1492,7 @@ void destroy(tr_scene *s)
     for (int k = 0; k < LOOKAHEAD; k++) {
         dev_free(s->d_order[k]);
         dev_free(s->d_bins[k]);
+        dev_free(s->d_recs[k]);
     }
     dev_free(s->d_bin_need);
     dev_free(s->d_overflow_seq);
@@ -1489,6 +1508,7 @@ void destroy(tr_scene *s)
     }
     for (tr_scene::GroupSet &g : s->grp) {
         dev_free(g.bins);
+        dev_free(g.recs);
         dev_free(g.count);
         dev_free(g.order);
         dev_free(g.d_tables);
@@ -1617,13 +1637,19 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     for (int k = 0; k < LOOKAHEAD; k++)
         if ((st = dev_alloc(&s->d_order[k], (size_t)s->n_tiles_full * ORDER_LISTS))) return st;
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
-    uint64_t cap = o.bin_capacity ? o.bin_capacity : 256;  // per tile; grows on overflow
-    if (cap > mesh->n_tri) cap = mesh->n_tri;               // a bin never holds more than all polygons
+    // records in a pass's pool = all its (polygon, tile) pairs.  Automatic: eight per polygon (the reference's
+    // model at 4096^2 has eight per drawn polygon, four per polygon), at least 65 536 and at most 4 Mi records -- 6 MiB
+    // to 384 MiB per pool; a pass that wants more makes the pools grow (and is rendered again)
+    uint64_t cap = o.bin_capacity ? o.bin_capacity : (uint64_t)mesh->n_tri * 8u;
+    if (!o.bin_capacity) cap = cap < 65536u ? 65536u : cap > (4u << 20) ? (4u << 20) : cap;
     if (cap < 64) cap = 64;
-    s->bin_cap = (uint32_t)cap;
+    if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
+    s->pool_cap = (uint32_t)cap;
     s->rec_pieces = (pipe == P_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    for (int k = 0; k < LOOKAHEAD; k++)
-        if ((st = dev_alloc(&s->d_bins[k], (size_t)bin_tiles(s) * s->bin_cap * s->rec_pieces))) return st;
+    for (int k = 0; k < LOOKAHEAD; k++) {
+        if ((st = dev_alloc(&s->d_bins[k], (size_t)s->pool_cap * s->rec_pieces))) return st;
+        if ((st = dev_alloc(&s->d_recs[k], (size_t)(mesh->n_tri ? mesh->n_tri : 1u) * s->rec_pieces))) return st;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream, hipStreamNonBlocking));
     for (int k = 0; k < RING; k++) {
         HIP_TRY(hipEventCreateWithFlags(&s->ev_setup[k], hipEventDisableTiming));

@@ -261,14 +261,15 @@ TR_HD float fma_est(float a, float b, float c)
 #endif
 }
 
-TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool cells, uint32_t &lo, uint32_t &hi)
+// (bx0 .. by1: the polygon's clamped box; (x0, y0): its vertex 0; a0, a1, b0, b1: the edge vectors from it as the
+// record holds them -- Edge::a0 .. b1, edge_setup)
+TR_HD void pair_masks(int32_t bx0, int32_t bx1, int32_t by0, int32_t by1, int32_t x0, int32_t y0, float a0, float a1, float b0,
+                      float b1, int32_t tile_x0, int32_t tile_y0, bool cells, uint32_t &lo, uint32_t &hi)
 {
-    const PairBox pb = pair_box(r.bx0, r.bx1, r.by0, r.by1, tile_x0, tile_y0);
+    const PairBox pb = pair_box(bx0, bx1, by0, by1, tile_x0, tile_y0);
     lo = hi = 0u;
     if (pb.ax0 > pb.ax1 || pb.ay0 > pb.ay1) return;
     // orientation-normalised edge constants (cross.z > 0), as the tile kernel uses them
-    float a0 = (float)isub(r.x1, r.x0), a1 = (float)isub(r.x2, r.x0);
-    float b0 = (float)isub(r.y1, r.y0), b1 = (float)isub(r.y2, r.y0);
     float cz = a0 * b1 - a1 * b0;
     if (cz < 0.0f) {
         a0 = -a0; a1 = -a1; b0 = -b0; b1 = -b1;
@@ -276,7 +277,7 @@ TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool
     }
     const bool small = cells && pb.nch <= SCAN_MAX_CHUNKS;
     const int32_t org_x = small ? pb.xs : tile_x0, org_y = small ? pb.ay0 : tile_y0;
-    const float ox = (float)isub(r.x0, org_x), oy = (float)isub(r.y0, org_y);
+    const float ox = (float)isub(x0, org_x), oy = (float)isub(y0, org_y);
     const float e0x = b1, e0y = -a1, e1x = -b0, e1y = a0, e2x = b0 - b1, e2y = a1 - a0;
     const float e0 = a1 * oy - ox * b1, e1 = ox * b0 - a0 * oy;
     const float e2 = cz - (e0 + e1);
@@ -327,6 +328,12 @@ TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool
             }
         }
     }
+}
+
+TR_HD void pair_masks(const RasterRec &r, int32_t tile_x0, int32_t tile_y0, bool cells, uint32_t &lo, uint32_t &hi)
+{
+    const Edge e = edge_setup(r);
+    pair_masks(r.bx0, r.bx1, r.by0, r.by1, r.x0, r.y0, e.a0, e.a1, e.b0, e.b1, tile_x0, tile_y0, cells, lo, hi);
 }
 
 // Block columns of the tile (8 pixels wide, bit i) that can hold a fragment of a pair, from its masks:

@@ -155,37 +155,36 @@ enum DevErr : uint32_t {
     DE_BIN_OVERFLOW = 1u << 4
 };
 
-// Triangle bins: tile t owns records [t*bin_cap, (t+1)*bin_cap) of `bins`.  tile_count[t] is bumped
-// with one atomic per (polygon, tile) pair and may run past bin_cap; entries beyond it are dropped,
-// DE_BIN_OVERFLOW is raised and bin_need records the largest count seen so the host can grow the
-// bins and render the frame again.
-// One entry of the tile kernel's work list (k_order).
-struct alignas(8) WorkItem {
+// Triangle bins: a pass has a POOL of `pool_cap` records; k_order gives tile t the records
+// [offset, offset + count) of it (WorkItem) -- exactly as many as k_setup counted.  Should the pairs of a
+// whole pass exceed the pool, DE_BIN_OVERFLOW is raised and bin_need records how many the pass wanted, so that the
+// host can grow the pools and render the frame again.
+// One entry of the tile kernel's work lists (k_order).
+struct alignas(16) WorkItem {
     uint32_t tile, count;
+    uint32_t offset;  // the tile's first record in the pool
+    uint32_t pad;
 };
 
 struct SetupArgs {
     DevMesh mesh;
     DevFrame frame;
     DevUniforms u;
-    uint32_t *tile_count;
-    Piece *bins;        // n_tiles x bin_cap records of rec_pieces x 16 B
-    uint32_t bin_cap;
+    uint32_t *tile_count;   // n_tiles counters, then 16 words (k_order's list lengths of a per-frame launch, the pool cursor)
+    Piece *recs;            // n_tri records of rec_pieces x 16 B: every polygon's record, once (k_setup -> k_bin)
+    Piece *bins;            // the pool: pool_cap records
+    uint32_t pool_cap;
     uint32_t rec_pieces;
-    uint32_t *bin_need;
     uint32_t *err;
     uint32_t *alarm;    // page-locked host word (mapped): set to 1 with whatever is raised in `err` (see TileArgs)
-    // overflow bookkeeping: the smallest `pass_seq` of a pass that overflowed a bin (atomic minimum)
-    unsigned long long *overflow_seq;
-    unsigned long long pass_seq;
     // 1: the tile kernel resolves small pairs as scan-line items (shared form): they get cell masks; 0: every pair
     // gets the block columns (pair_masks, tr_shaders.h)
     uint32_t cells;
 };
 
 struct TileArgs {
-    const Piece *bins;
-    uint32_t bin_cap;
+    const Piece *bins;   // the pass's pool
+    uint32_t pool_cap;
     uint32_t rec_pieces;
     // The pass's work lists (k_order, from this pass's counters): eight regions of n_tiles entries, region b =
     // the tiles of weight class b as (tile, polygons in its bin), the last region the empty tiles.
@@ -196,6 +195,11 @@ struct TileArgs {
     // instead of behind one more dependent load.
     uint32_t *tile_count;
     uint32_t list_len[8];
+    // k_order: where it writes each tile's first record (k_bin reads them), and the overflow bookkeeping -- how many
+    // records the pass wanted when the pool was too small, the smallest `pass_seq` of a pass that overflowed
+    uint32_t *bin_need;
+    unsigned long long *overflow_seq;
+    unsigned long long pass_seq;
     DevFrame frame;
     DevUniforms u;
     DevTextures tex;
