@@ -221,6 +221,7 @@ def main():
     else:
         fbs, fb_ptr = None, [None]  # N = 1: the scene's own frame slots
     torch.cuda.synchronize()
+    free_before_scene = torch.cuda.mem_get_info(device_index)[0]
     grouped = (not use_dist) and args.submit == "frames"
     # N > 1 through RCCL: every rank renders its band of a GROUP of frames per kernel launch and the bands are
     # exchanged frame by frame on a second stream while the next group renders (ShardedScene.render_frames)
@@ -623,6 +624,9 @@ def main():
             if per_frame_elapsed else None,
             "t_frame_us": t_frame,
             "latency_us": latency_us,
+            # everything the scene holds on the device once all the loops above have run (record pools, work lists,
+            # render targets of every frame in flight, textures): free memory before the scene minus free memory now
+            "device_memory_mb": round((free_before_scene - torch.cuda.mem_get_info(device_index)[0]) / 1e6, 1),
             "readback_inclusive_mpixels_per_s": round(n_shaded / readback / 1e6, 1) if readback else None,
             "readback_inclusive_frame_us": round(readback * 1e6, 1) if readback else None,
             "parity_vs_oracle": {"ok": parity_ok, "max_abs_rgb_diff": int(diff.max()), "tolerance": tol},

@@ -24,10 +24,10 @@ for name, flags in CONFIGS:
         continue
     j = json.loads(line[-1])
     out[name] = j
-    print("%-62s %8.1f us/frame (per-frame calls %.1f, unfused %.1f)  k_tile %s us/frame x %d  frac %.3f  parity %s  cpu %s" % (
+    print("%-62s %8.1f us/frame (per-frame calls %.1f, unfused %.1f)  k_tile %s us/frame x %d  frac %.3f  parity %s  mem %s MB  cpu %s" % (
         name, j["ms_per_step"] * 1e3, (j.get("per_frame_protocol") or {}).get("ms_per_step", 0.0) * 1e3,
         (j.get("per_frame_protocol") or {}).get("unfused_ms_per_step", 0.0) * 1e3,
-        j["kernel_us_per_frame"].get("k_tile"), j["config"]["frames_per_launch"], j["roofline"]["frac"], j["parity_vs_oracle"]["ok"],
+        j["kernel_us_per_frame"].get("k_tile"), j["config"]["frames_per_launch"], j["roofline"]["frac"], j["parity_vs_oracle"]["ok"], j.get("device_memory_mb"),
         j["cpu_baseline"]["sample"].split(",")[-1].strip() if j.get("cpu_baseline") else "-"), flush=True)
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "configs.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -8,6 +8,7 @@
 // entries in REVERSE polygon order to prove the resolve does not depend on order.
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -133,6 +134,19 @@ extern "C" uint32_t tr_emul_render(uint32_t W, uint32_t H, const tr_mesh *mesh, 
         tx.texel[k] = texel[k].data();
         tx.w[k] = tex[k].w;
         tx.h[k] = tex[k].h;
+    }
+    // the closure's images as one interleaved, tiled array, as the scene builds it (tr_texels.h) -- TR_EMUL_PLAIN_TEXELS=1:
+    // the plain images only
+    std::vector<uint32_t> packed;
+    {
+        bool same = true;
+        for (int k = 1; k < 4; k++) same = same && tex[k].w == tex[0].w && tex[k].h == tex[0].h;
+        const char *plain = getenv("TR_EMUL_PLAIN_TEXELS");
+        if (same && !(plain && atoi(plain))) {
+            const uint32_t *const image[4] = { texel[0].data(), texel[1].data(), texel[2].data(), texel[3].data() };
+            packed = pack_texels(pipe->p[pipe->n - 1].fs, image, tex[0].w, tex[0].h, tx.packed_bpr);
+            tx.packed = packed.data();
+        }
     }
     std::vector<float> rows((size_t)mesh->n_tri * TRI_FLOATS);
     for (uint32_t t = 0; t < mesh->n_tri; t++)

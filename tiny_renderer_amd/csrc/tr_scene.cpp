@@ -24,6 +24,7 @@
 #include "tr_math.h"
 #include "tr_powf.h"
 #include "tr_prepare.h"
+#include "tr_texels.h"
 #include "tr_types.h"
 
 namespace tr {
@@ -159,6 +160,7 @@ struct tr_scene {
     // device allocations
     float *d_tri = nullptr;
     uint32_t *d_texel[4] = { nullptr, nullptr, nullptr, nullptr };
+    uint32_t *d_packed = nullptr;  // the colour closure's images as one interleaved, tiled array (tr_texels.h)
     // Per-tile polygon counters (followed by k_order's 16 words).  Colour passes (the scene's band)
     // and depth passes (always the whole frame) have different tile grids, hence a state each.
     // SETS sets: the tile kernel of pass q zeroes set (q + SETS - 1) % SETS, which no pass before
@@ -1478,6 +1480,7 @@ void destroy(tr_scene *s)
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     dev_free(s->d_tri);
     for (int k = 0; k < 4; k++) dev_free(s->d_texel[k]);
+    dev_free(s->d_packed);
     if (s->setup_stream) (void)hipStreamSynchronize(s->setup_stream);
     for (int k = 0; k < RING; k++) {
         if (s->ev_setup[k]) (void)hipEventDestroy(s->ev_setup[k]);
@@ -1612,17 +1615,33 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->mesh.n_tri = mesh->n_tri;
 
     // textures: rgb8 -> rgba8 so a texel is one aligned dword fetch
+    std::vector<uint32_t> rgba[4];
+    bool same_size = true;
     for (int k = 0; k < 4; k++) {
         const size_t n = (size_t)tex[k].w * tex[k].h;
-        std::vector<uint32_t> rgba(n);
+        rgba[k].resize(n);
         for (size_t i = 0; i < n; i++)
-            rgba[i] = (uint32_t)tex[k].rgb[3 * i] | ((uint32_t)tex[k].rgb[3 * i + 1] << 8) |
-                      ((uint32_t)tex[k].rgb[3 * i + 2] << 16);
+            rgba[k][i] = (uint32_t)tex[k].rgb[3 * i] | ((uint32_t)tex[k].rgb[3 * i + 1] << 8) |
+                         ((uint32_t)tex[k].rgb[3 * i + 2] << 16);
         if ((st = dev_alloc(&s->d_texel[k], n))) return st;
-        HIP_TRY(hipMemcpy(s->d_texel[k], rgba.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_texel[k], rgba[k].data(), n * 4, hipMemcpyHostToDevice));
         s->tex.texel[k] = s->d_texel[k];
         s->tex.w[k] = tex[k].w;
         s->tex.h[k] = tex[k].h;
+        same_size = same_size && tex[k].w == tex[0].w && tex[k].h == tex[0].h;
+    }
+    // ... and, when they all have one size, the images the colour closure reads as ONE array: interleaved texel by
+    // texel, tiled into 128-byte blocks (tr_texels.h; fetch_texels, tr_shaders.h)
+    static const bool plain_texels = getenv("TR_PLAIN_TEXELS") && atoi(getenv("TR_PLAIN_TEXELS"));  // test hook
+    if (same_size && !plain_texels) {
+        const int fs = kPipelines[pipe].pass[kPipelines[pipe].n_passes - 1].fs;
+        const uint32_t *const image[4] = { rgba[0].data(), rgba[1].data(), rgba[2].data(), rgba[3].data() };
+        uint32_t bpr = 0;
+        const std::vector<uint32_t> packed = pack_texels(fs, image, tex[0].w, tex[0].h, bpr);
+        if ((st = dev_alloc(&s->d_packed, packed.size()))) return st;
+        HIP_TRY(hipMemcpy(s->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+        s->tex.packed = s->d_packed;
+        s->tex.packed_bpr = bpr;
     }
 
     // bins
@@ -1637,11 +1656,20 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     for (int k = 0; k < LOOKAHEAD; k++)
         if ((st = dev_alloc(&s->d_order[k], (size_t)s->n_tiles_full * ORDER_LISTS))) return st;
     if ((st = dev_alloc(&s->d_bin_need, 1))) return st;
-    // records in a pass's pool = all its (polygon, tile) pairs.  Automatic: eight per polygon (the reference's
-    // model at 4096^2 has eight per drawn polygon, four per polygon), at least 65 536 and at most 4 Mi records -- 6 MiB
-    // to 384 MiB per pool; a pass that wants more makes the pools grow (and is rendered again)
-    uint64_t cap = o.bin_capacity ? o.bin_capacity : (uint64_t)mesh->n_tri * 8u;
-    if (!o.bin_capacity) cap = cap < 65536u ? 65536u : cap > (4u << 20) ? (4u << 20) : cap;
+    // records in a pass's pool = all its (polygon, tile) pairs.  Automatic: twice an estimate from the frame and
+    // the polygon count -- a model that fills half the frame with half of its polygons facing the viewer has
+    // polygons with boxes of side s = sqrt(2 W H / n), each meeting (1 + s/128)(1 + s/16) tiles of 128x16: 5.0 pairs
+    // per polygon for the reference's model at 4096^2 (measured 2.4), 1.32 for its 8x8 grid at 8192^2 (measured
+    // 1.29) -- at least 65 536 records (6 MiB) and at most 16 Mi; a pass that wants more makes the pools grow (and is
+    // rendered again)
+    uint64_t cap = o.bin_capacity;
+    if (!cap) {
+        const double n = (double)(mesh->n_tri ? mesh->n_tri : 1u);
+        const double side = sqrt(2.0 * (double)width * (double)height / n);
+        const double pairs = 0.5 * (1.0 + side / (double)TILE_W) * (1.0 + side / (double)TILE_H) * n;
+        cap = (uint64_t)(2.0 * pairs);
+        cap = cap < 65536u ? 65536u : cap > (16u << 20) ? (16u << 20) : cap;
+    }
     if (cap < 64) cap = 64;
     if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
     s->pool_cap = (uint32_t)cap;

@@ -113,6 +113,10 @@ struct DevTextures {
     const uint32_t *texel[4];  // rgba8 (a = 0), row 0 = top; texture, normal_map,
                                // normal_map_tangent, specular_map
     uint32_t w[4], h[4];
+    // The images the scene's colour closure fetches, interleaved texel by texel and tiled into 128-byte blocks
+    // (fetch_texels, tr_shaders.h); null: the closure fetches each image on its own (images of different sizes).
+    const uint32_t *packed = nullptr;
+    uint32_t packed_bpr = 0;  // blocks per row of blocks
 };
 
 // The model as the vertex stage reads it: one 96-byte row per polygon, gathered from
