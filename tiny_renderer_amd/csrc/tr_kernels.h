@@ -19,7 +19,9 @@ namespace tr {
 // tile grid, record layout, bin capacity -- to the launcher.  launch_order reads each frame's counters and
 // work lists from the TILE kernel's table (TileArgs::tile_count / order / list_len).
 // Vertex stage: every polygon's record into a.recs, its tiles' counters bumped.
-int launch_setup(int vs_kind, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st,
+// `hurry`: nothing else is on the GPU and the caller's tile kernel waits for the chain (shapes for latency, not for
+// running beside a tile kernel).
+int launch_setup(int vs_kind, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bool hurry, hipStream_t st,
                  hipEvent_t start, hipEvent_t done);
 // Builds the tile kernel's work lists from the counters k_setup filled (same stream, after it) and gives every tile
 // its range of the pool.  `one`: the pass's arguments (a per-frame launch); `group`: the fused launch's table.
@@ -27,7 +29,8 @@ int launch_order(const TileArgs &one, uint32_t n_tiles, const TileArgs *group, u
                  hipEvent_t done);
 // Copies the records into the tiles' ranges, with each (polygon, tile) pair's coverage masks (same stream, after
 // launch_order); counts the counters back down to zero.
-int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
+int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bool hurry, hipStream_t st, hipEvent_t start,
+               hipEvent_t done);
 // tile_waves: 4, 8 or 16 wavefronts per tile workgroup (see tr_types.h); shared != 0: the waves share the
 // tile's bin and resolve through atomic keys instead of each owning a column of the tile (k_tile's
 // SHARED parameter; falls back to columns when n_polygons or a.bin_cap exceed the key's fields).

@@ -1450,13 +1450,15 @@ int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned lo
 int rec_pieces_for_vs(int vs) { return vs == VS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 int rec_pieces_for_fs(int fs) { return fs == FS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 
-int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start,
-                 hipEvent_t done)
+int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bool hurry, hipStream_t st,
+                 hipEvent_t start, hipEvent_t done)
 {
     if ((int)a.rec_pieces != rec_pieces_for_vs(vs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
     // (an empty mesh: the first workgroup still zeroes the pass's list words)
-    const uint32_t threads = group ? CHAIN_THREADS : 64u;
+    // (`hurry`: nothing else is on the GPU and the caller's tile kernel waits for this chain -- a lone frame, or the
+    // first group after a synchronisation: single waves, spread over four times as many compute units)
+    const uint32_t threads = hurry ? 64u : CHAIN_THREADS;
     const dim3 grid(a.mesh.n_tri ? (a.mesh.n_tri + threads - 1u) / threads : 1u, group ? n_frames : 1u), block(threads);
 #define TR_SETUP_CASE(V)                                                                   \
     case V:                                                                                \
@@ -1478,17 +1480,19 @@ int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_
     return 0;
 }
 
-int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done)
+int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bool hurry, hipStream_t st, hipEvent_t start,
+               hipEvent_t done)
 {
     if (a.mesh.n_tri == 0) return 0;
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
-    // polygons per wave: all 64 lanes in a fused launch (throughput: the fewer waves, the less the tile kernel of
-    // the group in front is disturbed); for a lone frame, which WAITS for the wave with the most (polygon, tile)
-    // pairs, 8 when the mesh is small (628 waves for 5 022 polygons)
+    // polygons per wave: all 64 lanes beside a running tile kernel (throughput: the fewer waves, the less it is
+    // disturbed); when the caller's tile kernel WAITS for this chain (`hurry`, see launch_setup) and the mesh is
+    // small, 8 -- the wave with the most (polygon, tile) pairs is the critical path (628 waves for 5 022 polygons:
+    // 13 us instead of 39)
     uint32_t polys = BIN_POLYS;
-    if (!group && (a.mesh.n_tri + polys - 1u) / polys < 512u) polys = 8u;
+    if (hurry && (uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 2048u) polys = 8u;
     const uint32_t lds = 0u, waves = (a.mesh.n_tri + polys - 1u) / polys;
-    const uint32_t per_group = group ? CHAIN_WAVES : 1u;
+    const uint32_t per_group = hurry ? 1u : CHAIN_WAVES;
     const dim3 grid((waves + per_group - 1u) / per_group, group ? n_frames : 1u), block(64u * per_group);
     if (a.rec_pieces == (uint32_t)REC_PIECES_LARGE) {
         if (group)

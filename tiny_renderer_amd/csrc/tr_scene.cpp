@@ -905,16 +905,16 @@ int run_pass(tr_scene *s, const PassDesc &p)
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
     // the chain: vertex stage + counting, work lists + pool ranges, records into the ranges
     if (!s->profiling) {
-        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, nullptr, nullptr);
+        int rc = launch_setup(p.vs, sa, nullptr, 0, chain_on_main, chain, nullptr, nullptr);
         if (rc) return launch_status(rc, "k_setup");
         rc = launch_order(ta, n_tiles_pass, nullptr, 0, chain, nullptr, s->mesh.n_tri ? nullptr : s->ev_setup[p_seq % RING]);
         if (rc) return launch_status(rc, "k_order");
-        rc = launch_bin(sa, nullptr, 0, chain, nullptr, s->ev_setup[p_seq % RING]);
+        rc = launch_bin(sa, nullptr, 0, chain_on_main, chain, nullptr, s->ev_setup[p_seq % RING]);
         if (rc) return launch_status(rc, "k_bin");
     } else {
         // profiling: timing events on the dispatches themselves, then the pipeline's event separately
         EventPair ep = { take_event(s), take_event(s), K_SETUP, 1u };
-        int rc = launch_setup(p.vs, sa, nullptr, 0, chain, ep.a, ep.b);
+        int rc = launch_setup(p.vs, sa, nullptr, 0, chain_on_main, chain, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
         s->events.push_back(ep);
         EventPair eo = { take_event(s), take_event(s), K_ORDER, 1u };
@@ -923,7 +923,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
         s->events.push_back(eo);
         if (s->mesh.n_tri) {
             EventPair eb = { take_event(s), take_event(s), K_BIN, 1u };
-            rc = launch_bin(sa, nullptr, 0, chain, eb.a, eb.b);
+            rc = launch_bin(sa, nullptr, 0, chain_on_main, chain, eb.a, eb.b);
             if (rc) return launch_status(rc, "k_bin");
             s->events.push_back(eb);
         }
@@ -1192,11 +1192,11 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             eo.a = take_event(s); eo.b = take_event(s);
             eb.a = take_event(s); eb.b = take_event(s);
         }
-        int rc = launch_setup(pass.vs, sa0, d_setup + (size_t)pi * G, g, chain, ep.a, ep.b);
+        int rc = launch_setup(pass.vs, sa0, d_setup + (size_t)pi * G, g, chain_on_main, chain, ep.a, ep.b);
         if (rc) return launch_status(rc, "k_setup");
         rc = launch_order(h_tile[(size_t)pi * G], n_tiles_pass, d_tile + (size_t)pi * G, g, chain, eo.a, eo.b);
         if (rc) return launch_status(rc, "k_order");
-        rc = launch_bin(sa0, d_setup + (size_t)pi * G, g, chain, eb.a, eb.b);
+        rc = launch_bin(sa0, d_setup + (size_t)pi * G, g, chain_on_main, chain, eb.a, eb.b);
         if (rc) return launch_status(rc, "k_bin");
         if (s->profiling) {
             s->events.push_back(ep);

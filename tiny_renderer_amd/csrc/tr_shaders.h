@@ -440,8 +440,10 @@ TR_HD uint32_t fetch_texel(const DevTextures &tex, int which, int dims, float u,
 // bytes (8x4, 4x4 or 4x2 texels): one coordinate computation and one load per fragment, and a wave's fragments --
 // a patch of the screen, hence a patch of the image whatever the orientation of the model's uv chart -- touch a
 // third to a half of the cache lines that rows of an image would (row-major, a 16x4 patch rotated by 90 degrees is
-// 16 lines).  Measured on the x64 grid at 8192^2 (specular, three images): texel fetches were 71 us of the tile
-// kernel's 307 us per frame.  Values are the images' own: nothing about the result changes.
+// 16 lines).  Worth 1-1.5 % of the tile kernel where a closure reads several images (x64 grid at 8192^2, specular:
+// 1300 -> 1216 us per four frames against the same build fetching image by image; darboux at 4096^2 209 -> 206);
+// nothing for one image -- the tile kernel waits for instruction issue, not for texels (profiles/r03_notes.md).
+// Values are the images' own: nothing about the result changes.
 // t0: `texture`; t1: normal_map (normal-map, specular closures) or normal_map_tangent (darboux: util.rs:62-63 scales
 // its coordinates by normal_map's size); t2: specular_map (specular closure)
 template <int FS>
