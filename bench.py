@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--exchange", choices=("rccl", "peer"), default=os.environ.get("TR_BENCH_EXCHANGE", "rccl"),
                     help="N>1: how the bands travel: torch.distributed all_gather (RCCL) or the library's "
                          "peer-to-peer band copies (tr_exchange_*)")
+    ap.add_argument("--sparse", action="store_true",
+                    help="N>1 with --exchange peer: send the band tile by tile, skipping tiles that are the cleared colour on "
+                         "both sides (tr_exchange_all_gather_tiles)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the render stream (no double buffering)")
     ap.add_argument("--submit", choices=("frames", "frame"), default="frames",
                     help="N=1: frames = tr_scene_render_frames (groups of frames per launch), frame = four calls per frame")
@@ -300,7 +303,10 @@ def main():
             if timing["on"]:
                 gather_started[b].record(comm_stream)
             if exchange is not None:
-                exchange.all_gather(b, rank * band_bytes, band_bytes, comm_stream.cuda_stream)
+                if args.sparse:
+                    exchange.all_gather_tiles(b, scene.band_tiles(fb_ptr[b]), comm_stream.cuda_stream)
+                else:
+                    exchange.all_gather(b, rank * band_bytes, band_bytes, comm_stream.cuda_stream)
             else:
                 dist.all_gather_into_tensor(fbs[b], chunks[b])
             gathered[b].record(comm_stream)
@@ -361,11 +367,14 @@ def main():
             break
     barrier()
     device_idle()
+    sent_before = exchange.bytes_sent() if exchange is not None else 0
     t0 = time.perf_counter()
     run(args.steps)
     device_idle()   # this rank's frames are complete (flush + torch.cuda.synchronize()) ...
     barrier()       # ... and so are everybody's: the clock stops at the slowest rank (max over ranks below)
     elapsed = time.perf_counter() - t0
+    # what this rank really pushed to its peers per frame of the timed loop (the library's count; dense: the band to each)
+    sent_per_frame = (exchange.bytes_sent() - sent_before) // max(args.steps, 1) if exchange is not None else None
     ok, status = clean_sync()
     if not ok:
         raise SystemExit("triangle bins overflowed inside the timed region: the timing is void")
@@ -607,8 +616,10 @@ def main():
                            "" if args.no_overlap else ", double-buffered: exchange of frame f under the render of f+1"))
                        if use_dist else "none"},
             "group_ranks": group_ranks if use_dist else 1,
-            # what every rank ships per frame: its band to each of the others (dense: the sparse exchange is not built)
-            "exchange_bytes_per_frame": int(band_bytes * (world - 1)) if use_dist else 0,
+            # what rank 0 ships per frame: its band to each of the others (--exchange peer: the library's count of the timed
+            # loop -- with --sparse only the tiles that are not the cleared colour on both sides)
+            "exchange_bytes_per_frame": (int(sent_per_frame) if sent_per_frame is not None else int(band_bytes * (world - 1))) if use_dist else 0,
+            "exchange_dense_bytes_per_frame": int(band_bytes * (world - 1)) if use_dist else 0,
             "scaling_measured": "unmeasured here: one GPU per box (SCALE is the driver's 8-GPU run)" if world == 1 else "this run",
             "frames_per_s": round(args.steps / elapsed, 1),
             "frames_per_s_orbit": round(orbit_frames / orbit_elapsed, 1) if orbit_elapsed and orbit_status == 0 else None,

@@ -230,6 +230,30 @@ void *tr_exchange_frame(tr_exchange *x, uint32_t slot);
 int tr_exchange_export(tr_exchange *x, void *record /* TR_EXCHANGE_HANDLE_BYTES */);
 int tr_exchange_connect(tr_exchange *x, const void *records /* n_ranks * TR_EXCHANGE_HANDLE_BYTES */);
 int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, void *hip_stream);
+/* The SPARSE form of the exchange: the band of `slot`'s frame that scene `s` renders goes to the peers tile by tile
+ * (128 x 16 pixels), and a tile that holds the cleared colour here AND held it the last time this rank wrote the
+ * peer's copy does not travel at all -- three quarters of a 4096x4096 frame of the reference's model.  The scene
+ * knows which tiles those are (the fast-clear flags of its frame buffers: tr_scene_band_tiles); the exchange keeps
+ * the record of what each peer's copy holds.  The slot must be the frame buffer the scene rendered into
+ * (tr_scene_set_frame_buffer_device / tr_scene_render_frames) and nobody else may write this rank's band of the
+ * peers' copies.  Same ordering and collective rules as tr_exchange_all_gather; a tr_exchange_all_gather on the slot
+ * in between is allowed (it resets the record).  TR_EXCHANGE_PEER: one kernel per peer storing through the mapped
+ * slots over xGMI.  TR_EXCHANGE_RCCL (a collective's sizes are fixed by the host before the frame's coverage is
+ * known) and frames whose width is not a multiple of 16: the dense exchange of the band's rows.
+ * tr_exchange_bytes_sent counts what really travelled (it waits for the device). */
+typedef struct tr_band_tiles {
+    const void *frame_buffer_device; /* the frame buffer the flags describe */
+    const uint32_t *clean_device;    /* tiles_x * tiles_y flags on the device, row-major: != 0 = the tile's pixels are zeros */
+    uint32_t width, height;          /* the frame */
+    uint32_t tiles_x, tiles_y;       /* tile grid of the band; tiles are 128 x 16 pixels */
+    int32_t first_tile_row;          /* tile row (y up, rows of 16 pixels from the bottom) of grid row 0 */
+    int32_t band_y0, band_y1;        /* scene rows [y0, y1), y up, that the scene renders; buffer row = height - 1 - y */
+} tr_band_tiles;
+/* Queues what is still held back of the scene's frames and describes the tiles of `frame_buffer_device` (one of the
+ * buffers the scene has rendered into; NULL = the current one).  The flags are read by work queued AFTER the frame
+ * on the scene's stream or on a stream that waits for it. */
+int tr_scene_band_tiles(tr_scene *s, const void *frame_buffer_device, tr_band_tiles *out);
+int tr_exchange_all_gather_tiles(tr_exchange *x, uint32_t slot, const tr_band_tiles *tiles, void *hip_stream);
 int tr_exchange_status(tr_exchange *x);
 int tr_exchange_read(tr_exchange *x, uint32_t slot, void *host, size_t bytes); /* waits for the device, copies a slot out */
 void tr_exchange_destroy(tr_exchange *x);

@@ -929,13 +929,15 @@ def test_rccl_exchange_behind_the_c_abi(built):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout + r.stderr)[-3000:]
 
 
-def test_peer_exchange_two_processes_one_gpu(diablo):
+@pytest.mark.parametrize("sparse", [False, True])
+def test_peer_exchange_two_processes_one_gpu(diablo, sparse):
     """The library's own frame exchange (tr_exchange_*: HIP IPC mapped frame slots, concurrent DMA-engine
     band copies, generation flags) with TWO rank processes sharing this box's one GPU: bench.py's N = 2
     code path end to end -- band scenes, two frame slots, exchange on a second stream, a moving-camera
     leg -- and its closing comparison of the assembled frame with the oracle (rank 0 exits non-zero on a
     mismatch, e.g. a band that arrived late or stale).  Cross-GPU coherence cannot show on one device;
-    that run is the driver's."""
+    that run is the driver's.  `sparse`: the band goes tile by tile (tr_exchange_all_gather_tiles) and the tiles that
+    are the cleared colour on both sides stay home -- the assembled frames must be the same, with fewer bytes pushed."""
     import os
     import subprocess
     import sys
@@ -943,7 +945,7 @@ def test_peer_exchange_two_processes_one_gpu(diablo):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--exchange", "peer", "--size", "1024",
-                        "--steps", "40", "--warmup", "5", "--no-cpu"], env=env, cwd=H.REPO, capture_output=True,
+                        "--steps", "40", "--warmup", "5", "--no-cpu"] + (["--sparse"] if sparse else []), env=env, cwd=H.REPO, capture_output=True,
                        text=True, timeout=420)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     import json
@@ -952,6 +954,13 @@ def test_peer_exchange_two_processes_one_gpu(diablo):
     assert j["n_gpus"] == 2 and j["group_ranks"] == 2 and j["parity_vs_oracle"]["ok"]
     assert "peer-to-peer" in j["config"]["sharding"] and len(j["per_rank"]) == 2
     assert j["per_rank"][0]["band_rows"] == [0, 512] and j["per_rank"][1]["band_rows"] == [512, 1024]
+    dense = 512 * 1024 * 3
+    assert j["exchange_dense_bytes_per_frame"] == dense
+    if sparse:
+        # the model covers the middle of the frame: most tiles of the band are the cleared colour and stay home
+        assert 0 < j["exchange_bytes_per_frame"] < dense // 2, j["exchange_bytes_per_frame"]
+    else:
+        assert j["exchange_bytes_per_frame"] == dense
 
 
 def _exchange_rank(rank, q_in, q_out, participate):

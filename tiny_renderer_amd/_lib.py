@@ -59,6 +59,13 @@ class FrameParams(C.Structure):
                 ("up", C.c_float * 3)]
 
 
+class BandTiles(C.Structure):
+    """tr_band_tiles (include/tiny_renderer.h): a scene's band of a frame buffer, tile by tile."""
+    _fields_ = [("frame_buffer_device", C.c_void_p), ("clean_device", C.c_void_p), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("first_tile_row", C.c_int32),
+                ("band_y0", C.c_int32), ("band_y1", C.c_int32)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("frames", C.c_uint64)]
 
@@ -115,6 +122,8 @@ SYMBOLS = {
     "tr_exchange_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_exchange_all_gather": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "tr_exchange_all_gather_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(BandTiles), C.c_void_p]),
+    "tr_scene_band_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BandTiles)]),
     "tr_exchange_status": (C.c_int, [C.c_void_p]),
     "tr_exchange_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "tr_exchange_destroy": (None, [C.c_void_p]),

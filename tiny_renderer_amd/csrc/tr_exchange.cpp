@@ -125,7 +125,12 @@ struct tr_exchange {
     std::vector<hipEvent_t> copy_done;             // [rank]
     hipEvent_t fork = nullptr;
     uint32_t generation[MAX_SLOTS] = {};
-    uint64_t bytes_sent = 0;  // bytes this rank has pushed to its peers so far
+    uint64_t bytes_sent = 0;  // bytes this rank has pushed to its peers so far (dense calls)
+    // sparse calls (tr_exchange_all_gather_tiles): per slot, for each peer, which tiles of THIS rank's band hold zeros in
+    // the peer's copy -- [peer][tile], 0 = unknown -- and the device's count of the bytes those calls pushed
+    uint32_t *remote_clean[MAX_SLOTS] = {};
+    uint32_t remote_tiles[MAX_SLOTS] = {};
+    unsigned long long *d_tile_bytes = nullptr;
     uint32_t **d_wait_list = nullptr;  // device array of flag pointers for the arrival wait: [slot][peer]
     uint32_t **d_open_list = nullptr;  // ... and of the peers' "open" flags this rank stores into: [slot][peer]
     bool connected = false;
@@ -273,6 +278,86 @@ int tr_exchange_connect(tr_exchange *x, const void *blobs)
     return TR_OK;
 }
 
+namespace {
+// The peer transport's exchange of slot `slot`: this rank's part goes to every peer either as the byte range
+// [offset, offset + bytes) through the DMA engines (tiles == nullptr) or tile by tile through k_push_tiles.
+int peer_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, const tr_band_tiles *tiles, hipStream_t stream)
+{
+    const uint32_t g = x->generation[slot] + 1u;
+    const uint32_t r = x->rank;
+    tr::DevFrame frame = {};
+    if (tiles) {
+        frame.width = tiles->width;
+        frame.height = tiles->height;
+        frame.band_y0 = tiles->band_y0;
+        frame.band_y1 = tiles->band_y1;
+        frame.ntx = tiles->tiles_x;
+        frame.nty = tiles->tiles_y;
+        frame.ty_base = tiles->first_tile_row;
+        const uint32_t n_tiles = frame.ntx * frame.nty;
+        if (x->remote_tiles[slot] != n_tiles) {  // first sparse call on the slot (or another grid): nothing is known
+            if (x->remote_clean[slot]) {
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipFree(x->remote_clean[slot]));
+                x->remote_clean[slot] = nullptr;
+            }
+            HIP_TRY(hipMalloc((void **)&x->remote_clean[slot], (size_t)x->n_ranks * (n_tiles ? n_tiles : 1u) * 4u));
+            HIP_TRY(hipMemsetAsync(x->remote_clean[slot], 0, (size_t)x->n_ranks * (n_tiles ? n_tiles : 1u) * 4u, stream));
+            x->remote_tiles[slot] = n_tiles;
+        }
+        if (!x->d_tile_bytes) {
+            HIP_TRY(hipMalloc((void **)&x->d_tile_bytes, sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(x->d_tile_bytes, 0, sizeof(unsigned long long), stream));
+        }
+    } else if (x->remote_clean[slot]) {
+        // a dense exchange rewrites the peers' copies of the band whatever they held: the record starts over
+        HIP_TRY(hipMemsetAsync(x->remote_clean[slot], 0, (size_t)x->n_ranks * (x->remote_tiles[slot] ? x->remote_tiles[slot] : 1u) * 4u,
+                               stream));
+    }
+    // 1. my slot is open for generation g -- ordered after everything the caller queued on `stream`
+    //    (its consumer of the slot's previous content, and the render of this band)
+    if (x->n_ranks > 1) {
+        int rc = tr::launch_flags_store_all(x->d_open_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g, stream);
+        if (rc) return tr::fail(TR_E_HIP, "flag store launch failed");
+    }
+    HIP_TRY(hipEventRecord(x->fork, stream));
+    // 2. per peer: wait for its "open", send my band (DMA engines, or the tile kernel), say "arrived"
+    for (uint32_t p = 0; p < x->n_ranks; p++) {
+        if (p == r) continue;
+        hipStream_t c = x->copy_stream[p];
+        HIP_TRY(hipStreamWaitEvent(c, x->fork, 0));
+        int rc = tr::launch_flag_wait(x->flags + FlagIndex::open(slot, p), g, x->flags + FlagIndex::error(), x->timeout_ticks, c);
+        if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
+        if (tiles) {
+            // (a peer that never opened its slot: the wait has set the error word and the kernel writes nothing)
+            rc = tr::launch_push_tiles(x->frame[slot], x->peer_frame[slot][p], tiles->clean_device,
+                                       x->remote_clean[slot] + (size_t)p * x->remote_tiles[slot], frame,
+                                       x->flags + FlagIndex::error(), x->d_tile_bytes, c);
+            if (rc) return tr::fail(TR_E_HIP, "tile push launch failed");
+        } else if (bytes) {
+            HIP_TRY(hipMemcpyAsync(x->peer_frame[slot][p] + offset, x->frame[slot] + offset, bytes, hipMemcpyDeviceToDevice, c));
+        }
+        // (after a timeout the peer is not told "arrived": tr_exchange_status reports TR_E_EXCHANGE on both sides)
+        rc = tr::launch_flag_store_unless(x->peer_flags[p] + FlagIndex::arrived(slot, r), g, x->flags + FlagIndex::error(), c);
+        if (rc) return tr::fail(TR_E_HIP, "flag store launch failed");
+        HIP_TRY(hipEventRecord(x->copy_done[p], c));
+    }
+    // 3. the caller's stream continues when my copies have left and every peer's band has arrived
+    for (uint32_t p = 0; p < x->n_ranks; p++)
+        if (p != r) HIP_TRY(hipStreamWaitEvent(stream, x->copy_done[p], 0));
+    if (x->n_ranks > 1) {
+        int rc = tr::launch_flags_wait_all(x->d_wait_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g,
+                                           x->flags + FlagIndex::error(), x->timeout_ticks, stream);
+        if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
+    }
+    // (only now: a call that failed half way has not used up the generation its peers are waiting for -- the
+    // exchange is unusable after such a failure, but the next call does not pretend to be a later generation)
+    x->generation[slot] = g;
+    if (!tiles) x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);
+    return TR_OK;
+}
+}  // namespace
+
 int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, void *stream_)
 {
     if (!x || !x->connected) return tr::fail(TR_E_INVALID, "tr_exchange_all_gather: not connected");
@@ -290,44 +375,36 @@ int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t 
         x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);
         return TR_OK;
     }
-    const uint32_t g = x->generation[slot] + 1u;
-    const uint32_t r = x->rank;
-    // 1. my slot is open for generation g -- ordered after everything the caller queued on `stream`
-    //    (its consumer of the slot's previous content, and the render of this band)
-    if (x->n_ranks > 1) {
-        int rc = tr::launch_flags_store_all(x->d_open_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g, stream);
-        if (rc) return tr::fail(TR_E_HIP, "flag store launch failed");
-    }
-    HIP_TRY(hipEventRecord(x->fork, stream));
-    // 2. per peer: wait for its "open", copy my band with the DMA engines, say "arrived"
-    for (uint32_t p = 0; p < x->n_ranks; p++) {
-        if (p == r) continue;
-        hipStream_t c = x->copy_stream[p];
-        HIP_TRY(hipStreamWaitEvent(c, x->fork, 0));
-        int rc = tr::launch_flag_wait(x->flags + FlagIndex::open(slot, p), g, x->flags + FlagIndex::error(), x->timeout_ticks, c);
-        if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
-        if (bytes)
-            HIP_TRY(hipMemcpyAsync(x->peer_frame[slot][p] + offset, x->frame[slot] + offset, bytes, hipMemcpyDeviceToDevice, c));
-        rc = tr::launch_flag_store(x->peer_flags[p] + FlagIndex::arrived(slot, r), g, c);
-        if (rc) return tr::fail(TR_E_HIP, "flag store launch failed");
-        HIP_TRY(hipEventRecord(x->copy_done[p], c));
-    }
-    // 3. the caller's stream continues when my copies have left and every peer's band has arrived
-    for (uint32_t p = 0; p < x->n_ranks; p++)
-        if (p != r) HIP_TRY(hipStreamWaitEvent(stream, x->copy_done[p], 0));
-    if (x->n_ranks > 1) {
-        int rc = tr::launch_flags_wait_all(x->d_wait_list + (size_t)slot * x->n_ranks, x->n_ranks, r, g,
-                                           x->flags + FlagIndex::error(), x->timeout_ticks, stream);
-        if (rc) return tr::fail(TR_E_HIP, "flag wait launch failed");
-    }
-    // (only now: a call that failed half way has not used up the generation its peers are waiting for -- the
-    // exchange is unusable after such a failure, but the next call does not pretend to be a later generation)
-    x->generation[slot] = g;
-    x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);
-    return TR_OK;
+    return peer_all_gather(x, slot, offset, bytes, nullptr, stream);
 }
 
-uint64_t tr_exchange_bytes_sent(tr_exchange *x) { return x ? x->bytes_sent : 0u; }
+int tr_exchange_all_gather_tiles(tr_exchange *x, uint32_t slot, const tr_band_tiles *tiles, void *stream_)
+{
+    if (!x || !x->connected || !tiles) return tr::fail(TR_E_INVALID, "tr_exchange_all_gather_tiles: not connected, or null tiles");
+    if (slot >= x->n_slots || tiles->frame_buffer_device != x->frame[slot])
+        return tr::fail(TR_E_INVALID, "tr_exchange_all_gather_tiles: the tiles must describe the slot's own frame buffer");
+    if ((size_t)tiles->width * tiles->height * 3u != x->frame_bytes || tiles->band_y0 < 0 || tiles->band_y0 > tiles->band_y1 ||
+        (uint32_t)tiles->band_y1 > tiles->height)
+        return tr::fail(TR_E_INVALID, "tr_exchange_all_gather_tiles: the frame does not match the exchange's");
+    // the band's rows in the buffer (row 0 = top): [height - y1, height - y0)
+    const size_t row = (size_t)tiles->width * 3u;
+    const size_t offset = (size_t)(tiles->height - (uint32_t)tiles->band_y1) * row;
+    const size_t bytes = (size_t)(tiles->band_y1 - tiles->band_y0) * row;
+    if (x->backend == TR_EXCHANGE_RCCL || tiles->width % 16u != 0u) return tr_exchange_all_gather(x, slot, offset, bytes, stream_);
+    HIP_TRY(hipSetDevice(x->device));
+    return peer_all_gather(x, slot, offset, bytes, tiles, (hipStream_t)stream_);
+}
+
+uint64_t tr_exchange_bytes_sent(tr_exchange *x)
+{
+    if (!x) return 0u;
+    unsigned long long tiles = 0;
+    if (x->d_tile_bytes) {  // (what the sparse calls pushed is counted on the device: waits for it)
+        (void)hipSetDevice(x->device);
+        if (hipMemcpy(&tiles, x->d_tile_bytes, sizeof tiles, hipMemcpyDeviceToHost) != hipSuccess) tiles = 0;
+    }
+    return x->bytes_sent + (uint64_t)tiles;
+}
 
 int tr_exchange_status(tr_exchange *x)
 {
@@ -371,6 +448,9 @@ void tr_exchange_destroy(tr_exchange *x)
     if (x->fork) (void)hipEventDestroy(x->fork);
     if (x->d_wait_list) (void)hipFree(x->d_wait_list);
     if (x->d_open_list) (void)hipFree(x->d_open_list);
+    for (uint32_t k = 0; k < MAX_SLOTS; k++)
+        if (x->remote_clean[k]) (void)hipFree(x->remote_clean[k]);
+    if (x->d_tile_bytes) (void)hipFree(x->d_tile_bytes);
     for (uint32_t s = 0; s < MAX_SLOTS; s++)
         if (x->frame[s]) (void)hipFree(x->frame[s]);
     if (x->flags) (void)hipFree(x->flags);

@@ -41,11 +41,17 @@ int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &fram
 // tiles that are zeros on both sides (fb_clean: the target's colour-clean flags; host_clean: the host buffer's own)
 int launch_read_back(const uint8_t *fb, uint8_t *host, const uint32_t *fb_clean, uint32_t *host_clean, const DevFrame &frame,
                      hipStream_t st);
+// The band's tiles of `fb` into a peer GPU's copy of the frame, skipping the tiles that are zeros on both sides
+// (k_push_tiles; remote_clean: this rank's record of the peer's copy; poisoned: the exchange's error word).
+int launch_push_tiles(const uint8_t *fb, uint8_t *peer, const uint32_t *fb_clean, uint32_t *remote_clean, const DevFrame &frame,
+                      const uint32_t *poisoned, unsigned long long *bytes, hipStream_t st);
 int launch_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32, int32_t *out_i32,
                     uint32_t *out_u8, float *out_div, float *out_div_ref, hipStream_t st);
 // Peer exchange flags (tr_exchange.cpp): system-scope store of a generation number; waits that poll
 // until flag >= value (as a wrapping distance) and raise *error after timeout_ticks of the 100 MHz wall clock
 int launch_flag_store(uint32_t *flag, uint32_t value, hipStream_t st);
+// ... unless *unless != 0 (the exchange's error word: a wait earlier on the queue timed out)
+int launch_flag_store_unless(uint32_t *flag, uint32_t value, const uint32_t *unless, hipStream_t st);
 int launch_flags_store_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, hipStream_t st);
 int launch_flag_wait(uint32_t *flag, uint32_t value, uint32_t *error, uint64_t timeout_ticks, hipStream_t st);
 int launch_flags_wait_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, uint32_t *error,

@@ -1289,6 +1289,42 @@ __global__ __launch_bounds__(256) void k_read_back(const uint8_t *__restrict__ f
     if (threadIdx.x == 0u) host_clean[t] = zeros ? 1u : 0u;
 }
 
+// The sparse form of the frame exchange between GPUs (tr_exchange_all_gather_tiles): this rank's band goes to a
+// peer's copy of the frame tile by tile, like k_read_back to the host -- a tile whose colour-clean flag is up holds
+// zeros here, and if this rank's record of the PEER's copy (`remote_clean`, kept by the exchange per slot and peer)
+// says the tile was zeros the last time it was written there, nothing crosses the link: three quarters of a 4096^2
+// frame of the reference's model.  `peer` is the peer's frame slot mapped into this process (HIP IPC); the stores
+// are plain stores over xGMI, made visible by the kernel's end and the system-scope flag store that follows it on
+// the stream.  `poisoned`: the exchange's error word -- after a peer failed to open its slot in time nothing is
+// written into it.  `bytes`: running count of what was pushed.
+__global__ __launch_bounds__(256) void k_push_tiles(const uint8_t *__restrict__ fb, uint8_t *__restrict__ peer,
+                                                    const uint32_t *__restrict__ fb_clean, uint32_t *remote_clean, DevFrame frame,
+                                                    const uint32_t *poisoned, unsigned long long *bytes)
+{
+    if (__hip_atomic_load(poisoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+    const uint32_t t = blockIdx.x;
+    const bool zeros = fb_clean[t] != 0u;
+    const bool remote_zeros = remote_clean[t] != 0u;
+    __syncthreads();  // (every thread has read the remote flag before thread 0 changes it)
+    if (zeros && remote_zeros) return;
+    const int32_t W = (int32_t)frame.width, H = (int32_t)frame.height;
+    const int32_t x0 = (int32_t)(t % frame.ntx) * TILE_W, y0 = (frame.ty_base + (int32_t)(t / frame.ntx)) * TILE_H;
+    uint32_t pieces = 0;
+    // TILE_H rows x 24 pieces of 16 B
+    for (uint32_t c = threadIdx.x; c < (uint32_t)TILE_H * 24u; c += 256u) {
+        const int32_t y = y0 + (int32_t)(c / 24u);
+        const int32_t xb = x0 * 3 + (int32_t)(c % 24u) * 16;
+        if (xb < W * 3 && y >= frame.band_y0 && y < frame.band_y1) {
+            const size_t at = (size_t)(H - 1 - y) * W * 3 + xb;
+            const uint4 v = zeros ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4 *>(fb + at);
+            *reinterpret_cast<uint4 *>(peer + at) = v;
+            pieces++;
+        }
+    }
+    if (pieces) atomicAdd(bytes, (unsigned long long)pieces * 16ull);
+    if (threadIdx.x == 0u) remote_clean[t] = zeros ? 1u : 0u;
+}
+
 // tr_selftest_device_math: the device forms of the casts and of the shared-reciprocal division,
 // applied to caller-chosen operands so the host can compare them with its own.
 __global__ __launch_bounds__(256) void k_selftest(const float *x, const float *d, uint32_t n, uint32_t *out_u32,
@@ -1353,9 +1389,12 @@ __global__ __launch_bounds__(256) void k_selftest_unary(int which, uint32_t firs
 // `timeout_ticks` of the 100 MHz wall clock (ten seconds unless the host says otherwise), raising the
 // error word instead of hanging the queue.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_flag_store(uint32_t *flag, uint32_t value)
+// (`unless`: the exchange's error word -- after a wait on this queue has timed out, what was to be announced may
+// not have happened: the peer is not told)
+__global__ __launch_bounds__(64) void k_flag_store(uint32_t *flag, uint32_t value, const uint32_t *unless)
 {
     if (threadIdx.x == 0u) {
+        if (unless && __hip_atomic_load(unless, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1397,12 +1436,14 @@ __global__ __launch_bounds__(64) void k_flags_wait_all(uint32_t *const *flags, u
 
 }  // namespace
 
-int launch_flag_store(uint32_t *flag, uint32_t value, hipStream_t st)
+int launch_flag_store_unless(uint32_t *flag, uint32_t value, const uint32_t *unless, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_flag_store, dim3(1), dim3(64), 0, st, flag, value);
+    hipLaunchKernelGGL(k_flag_store, dim3(1), dim3(64), 0, st, flag, value, unless);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }
+
+int launch_flag_store(uint32_t *flag, uint32_t value, hipStream_t st) { return launch_flag_store_unless(flag, value, nullptr, st); }
 
 int launch_flags_store_all(uint32_t *const *flags, uint32_t n, uint32_t skip, uint32_t value, hipStream_t st)
 {
@@ -1599,6 +1640,17 @@ int launch_read_back(const uint8_t *fb, uint8_t *host, const uint32_t *fb_clean,
     if (n_tiles == 0) return 0;
     if (frame.width % 16u) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_read_back, dim3(n_tiles), dim3(256), 0, st, fb, host, fb_clean, host_clean, frame);
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_push_tiles(const uint8_t *fb, uint8_t *peer, const uint32_t *fb_clean, uint32_t *remote_clean, const DevFrame &frame,
+                      const uint32_t *poisoned, unsigned long long *bytes, hipStream_t st)
+{
+    const uint32_t n_tiles = frame.ntx * frame.nty;
+    if (n_tiles == 0) return 0;
+    if (frame.width % 16u) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_push_tiles, dim3(n_tiles), dim3(256), 0, st, fb, peer, fb_clean, remote_clean, frame, poisoned, bytes);
     TR_LAUNCH_CHECK();
     return 0;
 }

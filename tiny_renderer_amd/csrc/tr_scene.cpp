@@ -2126,6 +2126,34 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
     return TR_OK;
 }
 
+int tr_scene_band_tiles(tr_scene *s, const void *frame_buffer_device, tr_band_tiles *out)
+{
+    if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int st = flush_clear_color(s);
+    if (st != TR_OK) return st;
+    st = submit_pending(s);
+    if (st != TR_OK) return st;
+    const uint8_t *fb = frame_buffer_device ? (const uint8_t *)frame_buffer_device : s->d_fb;
+    const uint32_t *clean = nullptr;
+    for (const tr_scene::FbFlags &f : s->fb_flags)
+        if (f.fb == fb) clean = f.clean;
+    if (!clean) return tr::fail(TR_E_INVALID, "tr_scene_band_tiles: the scene has not rendered into this frame buffer");
+    out->frame_buffer_device = fb;
+    out->clean_device = clean;
+    out->width = s->frame.width;
+    out->height = s->frame.height;
+    out->tiles_x = s->frame.ntx;
+    out->tiles_y = s->frame.nty;
+    out->first_tile_row = s->frame.ty_base;
+    out->band_y0 = s->frame.band_y0;
+    out->band_y1 = s->frame.band_y1;
+    // the flags now count as read by a consumer: a pass that overflowed its pool can no longer be repaired unseen
+    s->observed_seq = s->pass_seq;
+    s->quiescent = false;
+    return TR_OK;
+}
+
 void *tr_host_alloc(size_t bytes)
 {
     void *p = nullptr, *d = nullptr;

@@ -209,6 +209,13 @@ class Scene:
         n = check(load_library().tr_scene_debug_tile_stamps(self._h, out.ctypes.data, cap))
         return out[:n]
 
+    def band_tiles(self, frame_buffer_device=None):
+        """tr_scene_band_tiles: the tiles of one of the frame buffers this scene has rendered into (None: the current
+        one) with their cleared-colour flags -- what PeerExchange.all_gather_tiles sends by."""
+        out = _lib.BandTiles()
+        check(load_library().tr_scene_band_tiles(self._h, frame_buffer_device, C.byref(out)))
+        return out
+
     def profile_enable(self, on=True):
         check(load_library().tr_scene_profile_enable(self._h, 1 if on else 0))
 

@@ -284,6 +284,12 @@ class PeerExchange:
     def all_gather(self, slot, offset, nbytes, hip_stream):
         self._check(self._L.tr_exchange_all_gather(self._h, slot, offset, nbytes, hip_stream))
 
+    def all_gather_tiles(self, slot, tiles, hip_stream):
+        """The sparse exchange (tr_exchange_all_gather_tiles): `tiles` = Scene.band_tiles(self.frame_ptr(slot)) of the
+        scene that rendered this rank's band into the slot; tiles that are the cleared colour on both sides stay home."""
+        import ctypes as C
+        self._check(self._L.tr_exchange_all_gather_tiles(self._h, slot, C.byref(tiles), hip_stream))
+
     def read(self, slot, height, width):
         import numpy as np
         out = np.empty((height, width, 3), np.uint8)
