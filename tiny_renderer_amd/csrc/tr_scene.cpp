@@ -1096,7 +1096,9 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
     // the set's previous group must have left the GPU before its bins, counters and tables are written again;
     // this wait is also what keeps the host from running ahead of the GPU without bound
     if (gs.in_flight) {
-        if (s->group_seq - s->group_submitted >= (uint64_t)GROUP_SETS) {  // (cannot happen: submit_groups holds back two at most)
+        // (about to wait on the host: whatever tile kernels are still held back go to the device first -- a wait
+        // packet in front of them costs less than a GPU that runs dry while the host sleeps)
+        if (s->group_seq - s->group_submitted >= (uint64_t)GROUP_SETS || hipEventQuery(gs.ev_tile) != hipSuccess) {
             int sg = submit_groups(s, true);
             if (sg != TR_OK) return sg;
         }
@@ -1236,11 +1238,15 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
             ep.a = take_event(s);
             ep.b = take_event(s);
         }
-        int rc = launch_tile(pass.fs, ta0, tile_waves, shared, s->mesh.n_tri, d_tile + (size_t)pi * G, g, s->stream, ep.a, ep.b);
+        // (the group's "tiles done" event rides on its last tile kernel's own completion signal: a separate record
+        // is one more packet between this group's tile kernel and the next one's)
+        const bool last = pi + 1u == np;
+        int rc = launch_tile(pass.fs, ta0, tile_waves, shared, s->mesh.n_tri, d_tile + (size_t)pi * G, g, s->stream, ep.a,
+                             (!s->profiling && last) ? gs.ev_tile : ep.b);
         if (rc) return launch_status(rc, "k_tile");
         if (s->profiling) s->events.push_back(ep);
     }
-    HIP_TRY(hipEventRecord(gs.ev_tile, s->stream));
+    if (s->profiling) HIP_TRY(hipEventRecord(gs.ev_tile, s->stream));
     s->groups_unfenced = true;
     if (!s->own_stream) s->observed_seq = s->pass_seq;  // a caller's stream: handed on (see recover_from_overflow)
     return TR_OK;
