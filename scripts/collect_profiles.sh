@@ -45,4 +45,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYC
   rocprofv3 --pmc $set --kernel-trace -d "$out/sq_$n" -o out --output-format csv -- python3 scripts/frame_loop.py 4096 phong 32 \
       > "$out/sq_$n.log" 2>&1 || echo "counter set refused: $set"
 done
+echo "== pmc SQ_INSTS configs[4]"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --kernel-trace -d "$out/sqcfg4_insts" -o out --output-format csv -- python3 scripts/frame_loop.py 8192 specular 8 diablo 8 \
+    > "$out/sqcfg4_insts.log" 2>&1 || echo "counter set refused (configs[4])"
 find "$out" -name "*.csv" | wc -l

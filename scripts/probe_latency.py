@@ -9,7 +9,10 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 pipe = sys.argv[2] if len(sys.argv) > 2 else "phong"
 model = sys.argv[3] if len(sys.argv) > 3 else "diablo"
 mesh, texs = T.load_assets(find_assets(model))
-s = T.Scene(size, size, mesh, texs, pipe)
+kw = {}
+if os.environ.get("TILE_WAVES"): kw["tile_waves"] = int(os.environ["TILE_WAVES"])
+if os.environ.get("TILE_MODE"): kw["tile_mode"] = int(os.environ["TILE_MODE"])
+s = T.Scene(size, size, mesh, texs, pipe, **kw)
 def step():
     s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()
 for _ in range(10):

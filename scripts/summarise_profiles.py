@@ -36,7 +36,7 @@ def one(pattern):
 def kernel_of(name):
     if "k_tile" in name:
         return "k_tile_depth" if "<7," in name.replace(" ", "") or "FS_DEPTH" in name else "k_tile"
-    for k in ("k_setup", "k_order", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
+    for k in ("k_setup", "k_order", "k_bin", "k_read_back", "k_push_tiles", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
         if k in name:
             return k
     return name[:48]
@@ -109,6 +109,14 @@ if head is not None and kt.get("SQ_ACTIVE_INST_VALU") and kt.get("GRBM_GUI_ACTIV
     json.dump(db, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 json.dump({k: {c: round(v, 1) for c, v in cs.items()} for k, cs in sq.items() if k.startswith("k_")},
           open(os.path.join(dst, tag + "_pmc_sq_4096_phong.json"), "w"), indent=1, sort_keys=True)
+# configs[4]'s instruction counters (before / after): "before" = round 2's library measured with the same
+# command on the same box earlier this round (profiles/r03_notes.md), "after" = this build
+sq4 = counters("sqcfg4_*")
+if sq4.get("k_tile"):
+    json.dump({"workload": WORKLOADS["cfg4"][0], "per": "launch of 4 frames (mean over the launches of scripts/frame_loop.py 8192 specular 8 diablo 8)",
+               "before_round2_library": {"k_tile": {"SQ_INSTS_VALU": 628.4e6, "SQ_INSTS_SALU": 296.8e6, "SQ_INSTS_LDS": 21.0e6}, "note": "same command, same box, round 2's library (gpurun_out/r3c; profiles/r03_notes.md)"},
+               "after": {k: {c: round(v, 1) for c, v in cs.items()} for k, cs in sq4.items() if k.startswith("k_")}},
+              open(os.path.join(dst, tag + "_pmc_sq_cfg4.json"), "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, tag + "_bench_4096_phong.log")).read().strip().splitlines()[-1][:600])
 for w, e in db["workloads"].items():
     print("%-50s %s %.1f MB/launch of %d frames" % (w, e["kernel"], e["hbm_bytes_per_launch"] / 1e6, e["frames_per_launch"]))
