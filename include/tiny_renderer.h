@@ -100,7 +100,8 @@ typedef struct tr_options {
                                   whole tile (depth resolve through LDS atomics), 0 = automatic.
                                   Speed only: results do not depend on it. */
     uint32_t frames_per_launch; /* tr_scene_render_frames: frames rendered by one launch of each kernel (1..32), 0 =
-                                  automatic (by tile count: 4 at 4096x4096, 32 for small frames).  Speed only. */
+                                  automatic (by tile count: 4 at 4096x4096, 32 for small frames; the later groups of
+                                  a call of sixteen groups or more grow up to 32 frames).  Speed only. */
 } tr_options;
 
 typedef struct tr_scene tr_scene;
@@ -133,8 +134,8 @@ int tr_scene_set_auto_group(tr_scene *s, int on); /* the same switch as TR_OPT_N
  *     tr_scene_set_camera(frames[i].look_from, .look_at, .up); tr_scene_render
  * produces, but the frames of a group (tr_scene_frames_per_launch of them) are rendered TOGETHER, by one launch of
  * each kernel: a lone frame leaves the GPU draining for a third of its tile kernel at 4096x4096, and a small frame
- * never fills it.  Each frame of a group has render targets of its own ("frame slots": z, colour, shadow buffer);
- * frame i uses slot i % frames_per_launch, so when the call returns its LAST frames_per_launch frames exist
+ * never fills it.  Each frame of a group has render targets of its own ("frame slots": z, colour, shadow buffer),
+ * handed out in rotation, so when the call returns its LAST tr_scene_frames_per_launch frames exist
  * (tr_scene_frames_kept).  The scene is left as the per-frame calls would leave it: light and camera of the last
  * frame, the last frame current for every getter and for a later tr_scene_render without clear.
  * frame_buffers_device: NULL (colour into the slots' own buffers) or n_frames device pointers of 3*W*H bytes each,

@@ -1383,13 +1383,48 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     int st = submit_pending(s);  // per-frame renders issued before go first
     if (st != TR_OK) return st;
     const uint32_t G = group_size(s);
-    if ((st = ensure_slots(s, G < n ? G : n)) != TR_OK) return st;
+    const uint32_t np = (uint32_t)kPipelines[s->pipeline].n_passes;
+    // The call's frames go out in groups of growing size: the first is the usual group (its tile kernel starts as
+    // early as it can), every later one up to four times the one before -- its setup chain still hides behind the tile
+    // kernel in front of it -- up to 32 frames per launch: between two tile kernels of a stream lie 6-12 us (the end of
+    // a kernel that wrote 200 MB, the dispatch of the next), which a call of 20 frames at 4096^2 pays once instead of
+    // four times (groups of 4 + 16) and a long call once per 32 frames.  Only when the group size is automatic, and
+    // within 8 GiB of frame slots / 16 GiB of record pools.
+    uint32_t Gmax = G;
+    // (a long call only -- sixteen groups or more: a slot's first frames are slower than its later ones (20 frames into
+    // 20 slots: tile kernel 31.2 us per frame, into 4 slots used five times each: 29.1), and a short call does not get
+    // that back)
+    if (!s->d_winner && !s->d_stamps && !s->frames_per_launch && !getenv("TR_GROUP") && n >= 16u * G) {
+        const uint64_t slot_bytes = (uint64_t)s->width * s->height * (4ull * np + 3ull);
+        const uint64_t set_bytes = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * np;
+        Gmax = (uint32_t)GROUP_MAX;
+        while (Gmax > G && (Gmax * slot_bytes > (8ull << 30) || (uint64_t)GROUP_SETS * Gmax * set_bytes > (16ull << 30))) Gmax /= 2u;
+        if (Gmax < G) Gmax = G;
+    }
+    static const uint32_t growth = getenv("TR_GROUP_GROWTH") ? (uint32_t)atoi(getenv("TR_GROUP_GROWTH")) : 4u;  // experiment hook
+    std::vector<uint32_t> sizes;
+    uint32_t largest = 0;
+    for (uint32_t left = n, g = 0; left; left -= g) {
+        g = sizes.empty() ? G : (growth * g < Gmax ? growth * g : Gmax);
+        g = g < left ? g : left;
+        sizes.push_back(g);
+        largest = g > largest ? g : largest;
+    }
+    // frame slots of the call: frame i renders into slot i mod S (the last S frames stay distinct).  A long call's slots
+    // and sets are made for the largest group the policy can reach, not for this call's own: calls of 100 and of 2 000
+    // frames allocate the same
+    const uint32_t S = Gmax > G ? Gmax : largest;
+    if ((st = ensure_slots(s, S)) != TR_OK) return st;
+    if (!fbs && Gmax > G)  // ... including the slots' own colour buffers (created and zero-filled on first use otherwise)
+        for (uint32_t k = 0; k < S; k++) {
+            uint8_t *unused = nullptr;
+            if ((st = slot_own_fb(s, (int)k, &unused)) != TR_OK) return st;
+        }
     // all the sets of groups in flight now (allocations of a few hundred MiB each: not in the middle of a call)
     for (int k = 0; k < GROUP_SETS && !s->d_winner; k++)
-        if ((st = ensure_group_set(s, s->grp[k], G)) != TR_OK) return st;
+        if ((st = ensure_group_set(s, s->grp[k], Gmax)) != TR_OK) return st;
     s->host_status = TR_OK;
     const uint64_t first_seq = s->pass_seq;
-    const uint32_t np = (uint32_t)kPipelines[s->pipeline].n_passes;
     if (s->d_winner) {
         // the winner tap is a single buffer: frame by frame through the ordinary path, slots all the same
         for (uint32_t i = 0; i < n; i++) {
@@ -1401,9 +1436,10 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
         }
     } else {
         int slot_of[GROUP_MAX];
-        for (uint32_t j = 0; j < (uint32_t)GROUP_MAX; j++) slot_of[j] = (int)j;
-        for (uint32_t i0 = 0; i0 < n; i0 += G) {
-            const uint32_t g = n - i0 < G ? n - i0 : G;
+        uint32_t i0 = 0;
+        for (size_t k = 0; k < sizes.size(); i0 += sizes[k], k++) {
+            const uint32_t g = sizes[k];
+            for (uint32_t j = 0; j < g; j++) slot_of[j] = (int)((i0 + j) % S);
             st = run_group(s, p + i0, fbs ? fbs + i0 : nullptr, slot_of, g, fbs && !(s->flags & TR_OPT_TRUST_FRAME_BUFFERS));
             if (st == TR_OK) st = submit_groups(s, false);
             if (st != TR_OK) {
@@ -1424,7 +1460,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
         const tr_frame_params &l = p[n - 1];
         memcpy(s->light, l.light, 12); memcpy(s->from, l.look_from, 12); memcpy(s->at, l.look_at, 12); memcpy(s->up, l.up, 12);
         s->z_fb_cleared = s->shadow_cleared = false;
-        if ((st = use_slot(s, (int)((n - 1) % G), fbs ? (uint8_t *)fbs[n - 1] : nullptr)) != TR_OK) return st;
+        if ((st = use_slot(s, (int)((n - 1) % S), fbs ? (uint8_t *)fbs[n - 1] : nullptr)) != TR_OK) return st;
     }
     // what is left of the call: its last min(n, G) frames
     const uint32_t kept = n < G ? n : G;
@@ -1432,7 +1468,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     s->tail.fbs.clear();
     if (fbs) s->tail.fbs.assign(fbs + (n - kept), fbs + n);
     s->tail.slot.resize(kept);
-    for (uint32_t k = 0; k < kept; k++) s->tail.slot[k] = (int)((n - kept + k) % G);
+    for (uint32_t k = 0; k < kept; k++) s->tail.slot[k] = (int)((n - kept + k) % (s->d_winner ? G : S));
     s->tail.first_seq = first_seq + (uint64_t)(n - kept) * np;
     if (fbs && n > kept) s->unreplayable_seq = s->tail.first_seq;  // older frames' buffers: theirs for good
     s->last_was_group = true;
