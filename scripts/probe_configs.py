@@ -20,7 +20,7 @@ for tag in (sys.argv[1:] or list(CFG)):
     s = T.Scene(size, size, mesh, texs, pipe, **kw)
     def step():
         s.clear(); s.set_light_direction(light(0.0)); s.set_camera(*camera(0.0)); s.render()
-    for _ in range(20): step()
+    for _ in range(160): step()   # (past the point where a long run's groups grow: a one-time allocation of a few ms)
     s.sync()
     t0 = time.perf_counter()
     for _ in range(steps): step()

@@ -250,6 +250,7 @@ struct tr_scene {
     };
     std::vector<DeferredFrame> deferred;
     bool auto_group = true;
+    uint32_t auto_streak = 0;  // groups that filled up inside a running loop since anything else needed the frames
     // The frames of the last tr_scene_render_frames call that still exist (the last `frames per group` of
     // them): what tr_scene_select_frame chooses from, and what is rendered again after a bin overflow.
     struct {
@@ -1002,6 +1003,24 @@ uint32_t group_size(const tr_scene *s)
     return g;
 }
 
+// Frames per launch that a LONG run of frames grows to (tr_scene_render_frames with sixteen groups or more; the
+// per-frame protocol after sixteen full groups in a row): between two tile kernels of a stream lie 6-12 us (the end of
+// a kernel that wrote 200 MB, the dispatch of the next), paid once per launch -- 32 frames per launch instead of 4 make
+// 4096^2 30.1 -> 28.7 us per frame.  Only when the group size is automatic, within 8 GiB of frame slots and 16 GiB of
+// record pools.  (Not for short runs: a slot's first frames are slower than its later ones -- 20 frames into 20 slots:
+// tile kernel 31.2 us per frame, into 4 slots used five times each: 29.1.)
+uint32_t long_run_group_size(const tr_scene *s)
+{
+    const uint32_t G = group_size(s);
+    if (s->d_winner || s->d_stamps || s->frames_per_launch || getenv("TR_GROUP")) return G;
+    const uint64_t np = (uint64_t)kPipelines[s->pipeline].n_passes;
+    const uint64_t slot_bytes = (uint64_t)s->width * s->height * (4ull * np + 3ull);
+    const uint64_t set_bytes = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * np;
+    uint32_t g = (uint32_t)GROUP_MAX;
+    while (g > G && (g * slot_bytes > (8ull << 30) || (uint64_t)GROUP_SETS * g * set_bytes > (16ull << 30))) g /= 2u;
+    return g < G ? G : g;
+}
+
 // Frame slots 1 .. n - 1 (slot 0 exists since tr_scene_create).  Their z memory needs no initial value:
 // a slot is only ever reached through a group's cleared frame, which writes every tile or raises its flag.
 int ensure_slots(tr_scene *s, uint32_t n)
@@ -1105,7 +1124,7 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
         HIP_TRY(hipEventSynchronize(gs.ev_tile));
     }
     gs.in_flight = false;
-    int st = ensure_group_set(s, gs, group_size(s));
+    int st = ensure_group_set(s, gs, g > group_size(s) ? g : group_size(s));
     if (st != TR_OK) return st;
     const uint32_t G = gs.frames;
     if (g == 0 || g > G) return tr::fail(TR_E_INVALID, "group larger than its set");
@@ -1319,6 +1338,7 @@ bool frame_is_groupable(const tr_scene *s)
 // is handed to the device now.
 int flush_deferred(tr_scene *s, bool hold_back)
 {
+    if (!hold_back) s->auto_streak = 0;
     if (s->deferred.empty()) return TR_OK;
     std::vector<tr_scene::DeferredFrame> fr;
     fr.swap(s->deferred);
@@ -1384,23 +1404,10 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     if (st != TR_OK) return st;
     const uint32_t G = group_size(s);
     const uint32_t np = (uint32_t)kPipelines[s->pipeline].n_passes;
-    // The call's frames go out in groups of growing size: the first is the usual group (its tile kernel starts as
-    // early as it can), every later one up to four times the one before -- its setup chain still hides behind the tile
-    // kernel in front of it -- up to 32 frames per launch: between two tile kernels of a stream lie 6-12 us (the end of
-    // a kernel that wrote 200 MB, the dispatch of the next), which a call of 20 frames at 4096^2 pays once instead of
-    // four times (groups of 4 + 16) and a long call once per 32 frames.  Only when the group size is automatic, and
-    // within 8 GiB of frame slots / 16 GiB of record pools.
-    uint32_t Gmax = G;
-    // (a long call only -- sixteen groups or more: a slot's first frames are slower than its later ones (20 frames into
-    // 20 slots: tile kernel 31.2 us per frame, into 4 slots used five times each: 29.1), and a short call does not get
-    // that back)
-    if (!s->d_winner && !s->d_stamps && !s->frames_per_launch && !getenv("TR_GROUP") && n >= 16u * G) {
-        const uint64_t slot_bytes = (uint64_t)s->width * s->height * (4ull * np + 3ull);
-        const uint64_t set_bytes = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * np;
-        Gmax = (uint32_t)GROUP_MAX;
-        while (Gmax > G && (Gmax * slot_bytes > (8ull << 30) || (uint64_t)GROUP_SETS * Gmax * set_bytes > (16ull << 30))) Gmax /= 2u;
-        if (Gmax < G) Gmax = G;
-    }
+    // The frames of a long call go out in groups of growing size (long_run_group_size): the first is the usual group
+    // (its tile kernel starts as early as it can), every later one up to four times the one before -- its setup chain
+    // still hides behind the tile kernel in front of it.
+    const uint32_t Gmax = n >= 16u * G ? long_run_group_size(s) : G;
     static const uint32_t growth = getenv("TR_GROUP_GROWTH") ? (uint32_t)atoi(getenv("TR_GROUP_GROWTH")) : 4u;  // experiment hook
     std::vector<uint32_t> sizes;
     uint32_t largest = 0;
@@ -2009,7 +2016,12 @@ int tr_scene_render(tr_scene *s)
     f.fb = s->d_fb;
     s->deferred.push_back(f);
     s->z_fb_cleared = s->shadow_cleared = false;  // the frame has consumed the clear
-    if (s->deferred.size() >= (size_t)group_size(s)) return flush_deferred(s, true);
+    // (a loop that has filled sixteen groups in a row without anybody looking at a frame is a long run: its groups grow)
+    const uint32_t target = s->auto_streak >= 16u ? long_run_group_size(s) : group_size(s);
+    if (s->deferred.size() >= (size_t)target) {
+        s->auto_streak++;
+        return flush_deferred(s, true);
+    }
     return TR_OK;
 }
 
