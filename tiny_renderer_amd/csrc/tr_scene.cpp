@@ -1098,6 +1098,25 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
     return TR_OK;
 }
 
+int slot_own_fb(tr_scene *s, int k, uint8_t **out);
+
+// Everything a long run's large groups need -- frame slots with their colour buffers, the sets of the groups in
+// flight -- allocated once, the first time the scene sees frames in bulk (a tr_scene_render_frames call of more than
+// one group, or a group that filled up under the per-frame protocol): a few milliseconds and, at 4096^2, 4 GiB that a
+// later, longer run must not pay for in its own time (a warm-up of five frames, then the timed twenty or two thousand).
+int prepare_long_runs(tr_scene *s, bool own_colour)
+{
+    const uint32_t g = long_run_group_size(s);
+    if (g <= group_size(s) || s->d_winner) return TR_OK;
+    int st = ensure_slots(s, g);
+    for (uint32_t k = 0; k < g && st == TR_OK && own_colour; k++) {
+        uint8_t *unused = nullptr;
+        st = slot_own_fb(s, (int)k, &unused);
+    }
+    for (int k = 0; k < GROUP_SETS && st == TR_OK; k++) st = ensure_group_set(s, s->grp[k], g);
+    return st;
+}
+
 int submit_groups(tr_scene *s, bool all);
 
 // Queues the setup of g <= frames-per-group cleared frames, one launch per kernel and pass.  Frame j takes
@@ -1369,6 +1388,7 @@ int flush_deferred(tr_scene *s, bool hold_back)
     st = submit_pending_tiles(s);
     if (st != TR_OK) return st;
     const uint32_t G = group_size(s);
+    if (hold_back && (st = prepare_long_runs(s, true)) != TR_OK) return st;  // (a loop that fills groups: see there)
     if ((st = ensure_slots(s, G < g ? g : G)) != TR_OK) return st;
     tr_frame_params params[GROUP_MAX];
     void *fbs[GROUP_MAX];
@@ -1421,12 +1441,8 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     // and sets are made for the largest group the policy can reach, not for this call's own: calls of 100 and of 2 000
     // frames allocate the same
     const uint32_t S = Gmax > G ? Gmax : largest;
+    if (n > G && (st = prepare_long_runs(s, fbs == nullptr)) != TR_OK) return st;
     if ((st = ensure_slots(s, S)) != TR_OK) return st;
-    if (!fbs && Gmax > G)  // ... including the slots' own colour buffers (created and zero-filled on first use otherwise)
-        for (uint32_t k = 0; k < S; k++) {
-            uint8_t *unused = nullptr;
-            if ((st = slot_own_fb(s, (int)k, &unused)) != TR_OK) return st;
-        }
     // all the sets of groups in flight now (allocations of a few hundred MiB each: not in the middle of a call)
     for (int k = 0; k < GROUP_SETS && !s->d_winner; k++)
         if ((st = ensure_group_set(s, s->grp[k], Gmax)) != TR_OK) return st;
