@@ -559,11 +559,15 @@ def main():
                         traffic_note = "workload not profiled"
                     elif db.get("source_fingerprint") != source_fingerprint():
                         traffic_note = "profiles/pmc_traffic.json was collected on other source (%s)" % db.get("source_fingerprint")
-                    elif abs(entry.get("frames_per_launch", 1) - frames_in_launch) > 0.05 * frames_in_launch:
-                        traffic_note = "profiled with %s frames per launch" % entry.get("frames_per_launch", 1)
                     elif dom in entry.get("per_kernel_hbm_bytes_per_launch", {}) or entry.get("kernel") == dom:
                         traffic = entry.get("per_kernel_hbm_bytes_per_launch", {}).get(dom, entry.get("hbm_bytes_per_launch"))
                         traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
+                        profiled_frames = entry.get("frames_per_launch", 1)
+                        if abs(profiled_frames - frames_in_launch) > 0.05 * frames_in_launch:
+                            # (a long run's launches hold more frames than the profiled loop's: the bytes are per
+                            # frame -- every frame has targets of its own -- and are scaled to this run's launch)
+                            traffic = int(round(traffic / profiled_frames * frames_in_launch))
+                            traffic_note += "; measured per launch of %s frames, scaled to %.2f" % (profiled_frames, frames_in_launch)
                 except Exception as e:  # a malformed file must not take the bench down
                     traffic, traffic_note = None, "unreadable pmc_traffic.json: %s" % e
             physical = round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None
@@ -607,8 +611,9 @@ def main():
             "data": data,
             "config": {"workload": workload, "n_shaded_per_frame": n_shaded,
                        "polygons": int(mesh["idx"].shape[0]),
-                       "submission": ("tr_scene_render_frames: %d frames per launch of each kernel, every frame into "
-                                      "render targets of its own" % frames_per_launch) if (grouped or grouped_dist)
+                       "submission": ("tr_scene_render_frames: %d frames per launch of each kernel (the later groups of a call "
+                                      "of sixteen groups or more grow to 32), every frame into render targets of its own"
+                                      % frames_per_launch) if (grouped or grouped_dist)
                        else "per frame: clear, set_light_direction, set_camera, render",
                        "frames_per_launch": frames_per_launch,
                        "sharding": ("screen row bands (tr_band_rows) + %s of the framebuffer%s" % (

@@ -1498,7 +1498,10 @@ int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
     // (an empty mesh: the first workgroup still zeroes the pass's list words)
     // (`hurry`: nothing else is on the GPU and the caller's tile kernel waits for this chain -- a lone frame, or the
-    // first group after a synchronisation: single waves, spread over four times as many compute units)
+    // first group after a synchronisation: single waves, spread over four times as many compute units.  A per-frame
+    // launch always: its chain is as long as the tile kernel it has to hide behind -- the throughput shapes made the
+    // unfused per-frame loop 65 us per frame at 4096^2 where these give 38)
+    hurry = hurry || !group;
     const uint32_t threads = hurry ? 64u : CHAIN_THREADS;
     const dim3 grid(a.mesh.n_tri ? (a.mesh.n_tri + threads - 1u) / threads : 1u, group ? n_frames : 1u), block(threads);
 #define TR_SETUP_CASE(V)                                                                   \
@@ -1531,6 +1534,7 @@ int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bo
     // small, 8 -- the wave with the most (polygon, tile) pairs is the critical path (628 waves for 5 022 polygons:
     // 13 us instead of 39)
     uint32_t polys = BIN_POLYS;
+    hurry = hurry || !group;  // (see launch_setup)
     if (hurry && (uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 2048u) polys = 8u;
     const uint32_t lds = 0u, waves = (a.mesh.n_tri + polys - 1u) / polys;
     const uint32_t per_group = hurry ? 1u : CHAIN_WAVES;
