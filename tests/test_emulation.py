@@ -55,6 +55,20 @@ def test_diablo_800(diablo, pipe):
         assert fast > 9 * plain and fast > 10000, (fast, plain)
 
 
+@pytest.mark.parametrize("pipe", ("phong", "normal_map", "specular", "darboux"))
+def test_interleaved_texel_set_is_the_plain_images(synthetic, pipe, monkeypatch):
+    """The closures fetch their texels from ONE interleaved, tiled array (tr_texels.h: pack_texels / packed_index /
+    fetch_texels) when the four images have one size -- the default above -- and image by image otherwise: both forms
+    give the oracle's frame, on images whose sides are not multiples of the 8x4 / 4x4 / 4x2 blocks either."""
+    mesh, texs = synthetic
+    odd = [np.ascontiguousarray(t[:250, :203]) for t in texs]   # 203 x 250 texels: partial blocks on both sides
+    for images in (texs, odd):
+        monkeypatch.delenv("TR_EMUL_PLAIN_TEXELS", raising=False)
+        assert_same(*run_both(320, 240, mesh, images, pipe, 0.4, -0.7), pipe)
+        monkeypatch.setenv("TR_EMUL_PLAIN_TEXELS", "1")
+        assert_same(*run_both(320, 240, mesh, images, pipe, 0.4, -0.7), pipe)
+
+
 def test_african_head_default(african_head):
     mesh, texs = african_head
     assert_same(*run_both(800, 800, mesh, texs, "default", 0.0, 0.0), "default")

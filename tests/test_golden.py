@@ -50,3 +50,20 @@ def test_gpu_matches_fingerprints(built, name, W, Hh, ca, la, pipe):
     if pipe != "specular" or T.load_library().tr_specular_exact():
         assert G.sha(fb) == gold["fb"]
     s.close()
+
+
+def test_variant_hashes_are_consistent_with_the_oracle_fingerprints():
+    """tests/golden/variant_hashes.json (what every alternative reading of nalgebra's operation order would hash to for
+    the scene of INTEGRATION.md's Rust test): its normative entry is the committed oracle fingerprint of that scene, the
+    two readings the Rust test can tell apart really hash differently, and the text of INTEGRATION.md quotes the
+    normative hashes."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    v = json.load(open(os.path.join(here, "golden", "variant_hashes.json")))["variants"]
+    for pipe in ("phong", "specular", "darboux", "shadow"):
+        gold = GOLD["diablo/640x480/cam+0.70/light-1.10/%s" % pipe]
+        assert v["0"][pipe]["fb"] == gold["fb"] and v["0"][pipe]["z"] == gold["z"], pipe
+    assert v["1"]["phong"]["z"] != v["0"]["phong"]["z"] and v["1"]["phong"]["fb"] == v["0"]["phong"]["fb"]
+    assert v["2"]["phong"]["fb"] != v["0"]["phong"]["fb"] and v["2"]["phong"]["z"] != v["0"]["phong"]["z"]
+    text = open(os.path.join(os.path.dirname(here), "INTEGRATION.md")).read()
+    assert v["0"]["phong"]["fb"] in text and v["0"]["phong"]["z"] in text
+    assert v["1"]["phong"]["z"][:8] in text and v["2"]["phong"]["fb"][:8] in text
