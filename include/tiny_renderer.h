@@ -100,8 +100,9 @@ typedef struct tr_options {
                                   whole tile (depth resolve through LDS atomics), 0 = automatic.
                                   Speed only: results do not depend on it. */
     uint32_t frames_per_launch; /* tr_scene_render_frames: frames rendered by one launch of each kernel (1..32), 0 =
-                                  automatic (by tile count: 4 at 4096x4096, 32 for small frames; the later groups of
-                                  a call of sixteen groups or more grow up to 32 frames).  Speed only. */
+                                  automatic (by tile count: 4 at 4096x4096, 32 for small frames; a call of several
+                                  groups uses up to three times that per launch, a call of sixteen groups or more
+                                  grows to 32).  Speed only. */
 } tr_options;
 
 typedef struct tr_scene tr_scene;

@@ -16,7 +16,7 @@ def params(n, a0):
         p[i, 0:3] = light(a0 + 0.01 * i)
         p[i, 3:6], p[i, 6:9], p[i, 9:12] = camera(a0 + 0.01 * i)
     return p
-s.render_frames(params(8, 0.0)); s.sync()
+s.render_frames(params(int(os.environ.get("WARM", "8")), 0.0)); s.sync()
 for rep in range(3):
     time.sleep(0.02)
     p = params(steps, 0.1 * rep)

@@ -94,3 +94,84 @@ def test_bench_refuses_mismatched_world(built):
     r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def _sparse_worker(rank, world, port, W, Hh, q):
+    """The sparse exchange's PROTOCOL on the CPU (tr_exchange_all_gather_tiles / k_push_tiles, csrc): a rank sends a tile of
+    its band only if it is not the cleared colour, or if its record of the PEER's copy says the peer still holds
+    something else there -- and then it sends zeros; the record follows what was sent.  Tiles are the product's
+    128 x 16 pixels, bands the product's tr_band_rows.  Frames where the model moves out of tiles it covered before are
+    the interesting ones: a tile that became empty must be zeroed on the peer exactly once."""
+    import torch.distributed as dist
+    sys.path.insert(0, H.REPO)
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, sent_tiles, dense_tiles = True, 0, 0
+    try:
+        mesh, texs = T.synthetic_scene(n_lat=10, n_lon=20, tex_size=128)
+        mesh = dict(mesh, pos=(mesh["pos"] * np.float32(0.45)).astype(np.float32))   # a model that leaves most tiles empty
+        row0, row1 = T.band_rows(Hh, world, rank)
+        full = O.Scene(W, Hh, mesh, texs, "phong")
+        mine = O.Scene(W, Hh, mesh, texs, "phong")
+        mine.set_output_band(row0, row1)
+        frame = np.zeros((Hh, W, 3), np.uint8)                       # this rank's copy of the whole frame
+        TW, TH = 128, 16
+        # tiles are rows of 16 pixels counted from the BOTTOM of the frame (y up), clipped to the band
+        tiles = [(x0, max(row0, Hh - (ty + 1) * TH), min(row1, Hh - ty * TH))
+                 for ty in range((Hh + TH - 1) // TH) for x0 in range(0, W, TW)]
+        tiles = [(x0, r0, r1) for (x0, r0, r1) in tiles if r0 < r1]
+        remote_clean = {p: [False] * len(tiles) for p in range(world) if p != rank}   # "the peer's copy holds zeros"
+        for f, ca in enumerate([0.0, 0.9, 1.8, 0.9, 0.0, 2.7]):
+            for s_ in (full, mine):
+                s_.clear()
+                s_.set_light_direction(H.light(0.3))
+                s_.set_camera(*H.camera(ca))
+                assert s_.render() == 0
+            band = mine.get_frame_buffer()
+            frame[row0:row1] = band[row0:row1]
+            out = {p: [] for p in remote_clean}
+            for t, (x0, r0, r1) in enumerate(tiles):
+                px = band[r0:r1, x0:x0 + TW]
+                zeros = not px.any()
+                for p in remote_clean:
+                    dense_tiles += 1
+                    if zeros and remote_clean[p][t]:
+                        continue                                       # zeros here, zeros there: stays home
+                    out[p].append((t, None if zeros else px.copy()))
+                    remote_clean[p][t] = zeros
+                    sent_tiles += 1
+            got = [None] * world
+            dist.all_gather_object(got, (rank, tiles, out))
+            for (src, src_tiles, src_out) in got:
+                if src == rank:
+                    continue
+                for (t, px) in src_out[rank]:
+                    x0, r0, r1 = src_tiles[t]
+                    frame[r0:r1, x0:x0 + TW] = 0 if px is None else px
+            ok = ok and np.array_equal(frame, full.get_frame_buffer())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    q.put((rank, bool(ok), sent_tiles, dense_tiles))
+
+
+def test_sparse_tile_exchange_protocol(built):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, 512, 256, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[:2] for r in res) == [(r, True) for r in range(world)]
+    # most tiles never travel (the first frame sends every tile once: the peers' copies are unknown)
+    assert all(r[2] < 0.6 * r[3] for r in res), res

@@ -1431,6 +1431,23 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     static const uint32_t growth = getenv("TR_GROUP_GROWTH") ? (uint32_t)atoi(getenv("TR_GROUP_GROWTH")) : 4u;  // experiment hook
     std::vector<uint32_t> sizes;
     uint32_t largest = 0;
+    // A SHORT call (fewer than sixteen groups) is mostly start-up and gaps: it goes out in as few launches as groups of
+    // up to three times the usual size allow, all of about the same size (twenty frames at 4096^2: two launches of ten
+    // instead of five of four).
+    static const uint32_t short_factor = getenv("TR_SHORT_GROUPS") ? (uint32_t)atoi(getenv("TR_SHORT_GROUPS")) : 3u;  // experiment hook
+    const bool automatic = !s->d_winner && !s->d_stamps && !s->frames_per_launch && !getenv("TR_GROUP");
+    if (automatic && n > G && Gmax == G && short_factor > 1u) {
+        uint32_t cap = short_factor * G < (uint32_t)GROUP_MAX ? short_factor * G : (uint32_t)GROUP_MAX;
+        const uint32_t long_run = long_run_group_size(s);   // (slots and sets exist for that many: prepare_long_runs)
+        if (cap > long_run) cap = long_run;
+        const uint32_t k = (n + cap - 1u) / cap;
+        for (uint32_t i = 0, left = n; i < k; i++) {
+            const uint32_t g = (left + (k - i) - 1u) / (k - i);
+            sizes.push_back(g);
+            largest = g > largest ? g : largest;
+            left -= g;
+        }
+    } else
     for (uint32_t left = n, g = 0; left; left -= g) {
         g = sizes.empty() ? G : (growth * g < Gmax ? growth * g : Gmax);
         g = g < left ? g : left;
@@ -1445,7 +1462,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     if ((st = ensure_slots(s, S)) != TR_OK) return st;
     // all the sets of groups in flight now (allocations of a few hundred MiB each: not in the middle of a call)
     for (int k = 0; k < GROUP_SETS && !s->d_winner; k++)
-        if ((st = ensure_group_set(s, s->grp[k], Gmax)) != TR_OK) return st;
+        if ((st = ensure_group_set(s, s->grp[k], largest > Gmax ? largest : Gmax)) != TR_OK) return st;
     s->host_status = TR_OK;
     const uint64_t first_seq = s->pass_seq;
     if (s->d_winner) {
