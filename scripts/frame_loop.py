@@ -29,6 +29,10 @@ else:
     p = np.zeros((frames, 12), np.float32)
     p[:, 0:3] = light(0.0)
     p[:, 3:6], p[:, 6:9], p[:, 9:12] = camera(0.0)
-    s.render_frames(p)
-    print("frames", frames, "frames_per_launch", s.frames_per_launch)
+    # (the profilers' launches must all hold the same, known number of frames: groups of the scene's own size, call by
+    # call -- a single call of FRAMES frames would go out in fewer, larger groups)
+    g = s.frames_per_launch
+    for i in range(0, frames, g):
+        s.render_frames(p[i:i + g])
+    print("frames", frames, "frames_per_launch", g)
 print("status", s.sync())

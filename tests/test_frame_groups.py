@@ -94,6 +94,31 @@ def test_group_sizes_and_counts(small_synthetic, fpl, n):
     gpu.close()
 
 
+@pytest.mark.parametrize("n,launches", [(70, 4), (20, 2), (9, 1)])
+def test_group_sizes_of_long_and_short_calls(small_synthetic, n, launches):
+    """Automatic group sizes at 4096^2 (the usual group: 4 frames).  A call of sixteen groups or more grows its groups
+    (70 frames: 4 + 16 + 32 + 18), a shorter one goes out in as few launches as groups of up to twelve allow (20 frames:
+    10 + 10; 9 frames: one launch) -- and whatever the sizes, the frames the call leaves behind are the oracle's."""
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W = Hh = 4096
+    p = params(n, cam_step=0.09)
+    gpu = T.Scene(W, Hh, mesh, texs, "phong")
+    assert gpu.frames_per_launch == 4
+    gpu.profile_enable(True)
+    gpu.render_frames(p)
+    assert gpu.sync() == 0
+    prof = gpu.profile_read()
+    gpu.profile_enable(False)
+    assert prof["k_tile"]["launches"] == launches and prof["k_tile"]["frames"] == n, prof
+    # (the oracle renders only the frames that are left: 0.1 s each at this size)
+    kept = gpu.frames_kept()
+    assert kept == min(n, 4)
+    expect = [None] * (n - kept) + oracle_frames(W, Hh, mesh, texs, "phong", p[n - kept:])
+    check_kept(gpu, expect, "phong", n)
+    gpu.close()
+
+
 @pytest.mark.parametrize("pipe", ["phong", "darboux", "shadow"])
 @pytest.mark.parametrize("waves", [4, 8, 16])
 @pytest.mark.parametrize("mode", [1, 2])

@@ -1457,7 +1457,8 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     // frame slots of the call: frame i renders into slot i mod S (the last S frames stay distinct).  A long call's slots
     // and sets are made for the largest group the policy can reach, not for this call's own: calls of 100 and of 2 000
     // frames allocate the same
-    const uint32_t S = Gmax > G ? Gmax : largest;
+    // (never fewer slots than the frames the call leaves behind: its last min(n, G))
+    const uint32_t S = Gmax > G ? Gmax : (largest > (n < G ? n : G) ? largest : (n < G ? n : G));
     if (n > G && (st = prepare_long_runs(s, fbs == nullptr)) != TR_OK) return st;
     if ((st = ensure_slots(s, S)) != TR_OK) return st;
     // all the sets of groups in flight now (allocations of a few hundred MiB each: not in the middle of a call)
