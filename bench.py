@@ -338,6 +338,14 @@ def main():
 
     def device_idle():
         scene.flush()             # the scene may hold renders back to batch them: hand them over,
+        if not use_dist:
+            # ... wait for the scene's own stream first: hipStreamSynchronize wakes the thread 20-25 us sooner after a
+            # long wait than the device-wide hipDeviceSynchronize behind torch.cuda.synchronize (which then returns at
+            # once; scripts/probe_driver.py).  A frame status is taken by clean_sync(), not here.
+            try:
+                scene.sync()
+            except T.TinyRendererError:
+                pass
         torch.cuda.synchronize()  # then wait for every stream of the device
 
     from tiny_renderer_amd.sharded import any_rank

@@ -94,11 +94,11 @@ def test_group_sizes_and_counts(small_synthetic, fpl, n):
     gpu.close()
 
 
-@pytest.mark.parametrize("n,launches", [(70, 4), (20, 2), (9, 1)])
+@pytest.mark.parametrize("n,launches", [(70, 4), (20, 3), (9, 2)])
 def test_group_sizes_of_long_and_short_calls(small_synthetic, n, launches):
     """Automatic group sizes at 4096^2 (the usual group: 4 frames).  A call of sixteen groups or more grows its groups
-    (70 frames: 4 + 16 + 32 + 18), a shorter one goes out in as few launches as groups of up to twelve allow (20 frames:
-    10 + 10; 9 frames: one launch) -- and whatever the sizes, the frames the call leaves behind are the oracle's."""
+    (70 frames: 4 + 16 + 32 + 18), a shorter one starts with the usual group and doubles up to twelve (20 frames:
+    4 + 8 + 8; 9 frames: 4 + 5) -- and whatever the sizes, the frames the call leaves behind are the oracle's."""
     import tiny_renderer_amd as T
     mesh, texs = small_synthetic
     W = Hh = 4096

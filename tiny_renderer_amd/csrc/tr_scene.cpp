@@ -1431,21 +1431,23 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     static const uint32_t growth = getenv("TR_GROUP_GROWTH") ? (uint32_t)atoi(getenv("TR_GROUP_GROWTH")) : 4u;  // experiment hook
     std::vector<uint32_t> sizes;
     uint32_t largest = 0;
-    // A SHORT call (fewer than sixteen groups) is mostly start-up and gaps: it goes out in as few launches as groups of
-    // up to three times the usual size allow, all of about the same size (twenty frames at 4096^2: two launches of ten
-    // instead of five of four).
+    // A SHORT call (fewer than sixteen groups) is mostly start-up and gaps: its first group is the usual one -- the host
+    // has four frames to prepare, not ten, before the first kernel can start, and the chain in front of the first tile
+    // kernel is the short one -- and every later group up to twice the one before (its chain hides behind the tile
+    // kernel in front), up to three times the usual size: twenty frames at 4096^2 = 4 + 8 + 8, two gaps instead of four.
     static const uint32_t short_factor = getenv("TR_SHORT_GROUPS") ? (uint32_t)atoi(getenv("TR_SHORT_GROUPS")) : 3u;  // experiment hook
     const bool automatic = !s->d_winner && !s->d_stamps && !s->frames_per_launch && !getenv("TR_GROUP");
     if (automatic && n > G && Gmax == G && short_factor > 1u) {
         uint32_t cap = short_factor * G < (uint32_t)GROUP_MAX ? short_factor * G : (uint32_t)GROUP_MAX;
         const uint32_t long_run = long_run_group_size(s);   // (slots and sets exist for that many: prepare_long_runs)
         if (cap > long_run) cap = long_run;
-        const uint32_t k = (n + cap - 1u) / cap;
-        for (uint32_t i = 0, left = n; i < k; i++) {
-            const uint32_t g = (left + (k - i) - 1u) / (k - i);
+        for (uint32_t left = n, g = 0; left; left -= g) {
+            g = sizes.empty() ? G : (2u * g < cap ? 2u * g : cap);
+            // (the remainder in equal parts rather than a full group and a sliver)
+            const uint32_t parts = (left + g - 1u) / g;
+            g = (left + parts - 1u) / parts;
             sizes.push_back(g);
             largest = g > largest ? g : largest;
-            left -= g;
         }
     } else
     for (uint32_t left = n, g = 0; left; left -= g) {
