@@ -35,6 +35,19 @@ for ca in (0.0, 0.8, 1.9):
     got = np.empty((Hh, W, 3), np.uint8)
     TL.check(L.tr_exchange_read(h, 0, got.ctypes.data, got.nbytes))
     assert np.array_equal(got, cpu.get_frame_buffer()), "angle %.1f" % ca
+# the sparse call on the RCCL transport is answered with the dense all-gather of the band's rows (a collective's sizes
+# are fixed before the frame's coverage is known): same frame, and tiles that describe another buffer are refused
+for s in (gpu, cpu):
+    s.clear(), s.set_light_direction(H.light(-0.3)), s.set_camera(*H.camera(2.6)), s.render()
+tiles = gpu.band_tiles(slot)
+assert tiles.width == W and tiles.height == Hh and tiles.tiles_x == (W + 127) // 128 and tiles.band_y0 == 0 and tiles.band_y1 == Hh
+TL.check(L.tr_exchange_all_gather_tiles(h, 0, C.byref(tiles), None))
+TL.check(L.tr_exchange_read(h, 0, got.ctypes.data, got.nbytes))
+assert np.array_equal(got, cpu.get_frame_buffer()), "sparse call, RCCL transport"
+other = TL.BandTiles.from_buffer_copy(tiles)
+other.frame_buffer_device = (other.frame_buffer_device or 0) + 4096
+assert L.tr_exchange_all_gather_tiles(h, 0, C.byref(other), None) == TL.TR_E_INVALID
+assert L.tr_scene_band_tiles(gpu._h, C.c_void_p(12345), C.byref(other)) == TL.TR_E_INVALID   # a buffer the scene never rendered into
 # ranges that are not equal pieces in rank order are refused (rank 0 of 1: any offset > 0 leaves no room)
 assert L.tr_exchange_all_gather(h, 0, 16, W * Hh * 3, None) == TL.TR_E_INVALID
 assert L.tr_exchange_status(h) == 0
