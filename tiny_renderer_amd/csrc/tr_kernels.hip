@@ -1049,8 +1049,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 // shader.rs:318-333 / 386-401 for both pixels at once: texel, diffuse term,
                 // color_blend(c, 0, t) = (t * c + (1 - t) * 0.0) as u8 per channel
                 uint32_t ta, tb, unused1, unused2;
-                fetch_texels<FS>(a.tex, uu.x, vv.x, ea, ta, unused1, unused2);
-                fetch_texels<FS>(a.tex, uu.y, vv.y, eb, tb, unused1, unused2);
+                vec3 unused3;
+                fetch_texels<FS>(a.tex, uu.x, vv.x, ea, ta, unused1, unused2, unused3);
+                fetch_texels<FS>(a.tex, uu.y, vv.y, eb, tb, unused1, unused2, unused3);
                 f2 t = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
                 if (FS == FS_PHONG)
                     t = dot3_2(bar.x, bar.y, bar.z, t, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),

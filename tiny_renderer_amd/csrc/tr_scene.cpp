@@ -24,6 +24,7 @@
 #include "tr_math.h"
 #include "tr_powf.h"
 #include "tr_prepare.h"
+#include "tr_shaders.h"
 #include "tr_texels.h"
 #include "tr_types.h"
 

@@ -433,21 +433,30 @@ TR_HD uint32_t fetch_texel(const DevTextures &tex, int which, int dims, float u,
     return tex.texel[which][mul24(cy, tex.w[which]) + cx];  // sides are below 2^16 (checked at create)
 }
 
-// The texels one fragment needs, in ONE fetch.  A closure reads up to three images at the same (u, v); when the
-// images have the same size -- the reference's assets are all 1024 x 1024 -- the coordinate arithmetic is the same
-// three times over and the three loads go to three arrays.  The scene therefore keeps, beside the plain images, the
-// images ITS closure reads interleaved texel by texel (1, 2 or 4 words per texel) and tiled into blocks of 128
-// bytes (8x4, 4x4 or 4x2 texels): one coordinate computation and one load per fragment, and a wave's fragments --
-// a patch of the screen, hence a patch of the image whatever the orientation of the model's uv chart -- touch a
-// third to a half of the cache lines that rows of an image would (row-major, a 16x4 patch rotated by 90 degrees is
-// 16 lines).  Worth 1-1.5 % of the tile kernel where a closure reads several images (x64 grid at 8192^2, specular:
-// 1300 -> 1216 us per four frames against the same build fetching image by image; darboux at 4096^2 209 -> 206);
-// nothing for one image -- the tile kernel waits for instruction issue, not for texels (profiles/r03_notes.md).
-// Values are the images' own: nothing about the result changes.
-// t0: `texture`; t1: normal_map (normal-map, specular closures) or normal_map_tangent (darboux: util.rs:62-63 scales
-// its coordinates by normal_map's size); t2: specular_map (specular closure)
+// util.rs:51-56
+TR_HD vec3 decode_normal(uint32_t px)
+{
+    vec3 n = make3((float)(px & 0xFFu) / 255.0f - 0.5f, (float)((px >> 8) & 0xFFu) / 255.0f - 0.5f,
+                   (float)((px >> 16) & 0xFFu) / 255.0f - 0.5f);
+    return normalize3(n);
+}
+
+// The texels one fragment needs, in ONE fetch -- and the normal already decoded.  A closure reads up to three images at
+// the same (u, v); when the images have the same size -- the reference's assets are all 1024 x 1024 -- the coordinate
+// arithmetic is the same three times over and the three loads go to three arrays.  The scene therefore keeps, beside the
+// plain images, a texel set for ITS closure (tr_texels.h): per texel the colour image's texel and, for the closures with a
+// normal map, the decoded normal as three floats (with the specular exponent riding in the colour word's spare byte),
+// tiled into blocks of 128 bytes (8x4 or 4x2 texels): one coordinate computation and one 4- or 16-byte load per fragment,
+// a wave's fragments -- a patch of the screen, hence a patch of the image whatever the orientation of the model's uv
+// chart -- touch a third to a half of the cache lines that rows of an image would, and decode_normal's six divisions and
+// its square root are paid once per texel instead of once per fragment.  Values are the images' own and the decode is
+// the closures' own function (IEEE division and square root on the host, the device forms are proven equal to them, §3
+// of DESIGN.md): nothing about the result changes.
+// t0: `texture`; t1: the raw texel of normal_map (normal-map, specular closures) or normal_map_tangent (darboux:
+// util.rs:62-63 scales its coordinates by normal_map's size) when the set is absent; t2: specular_map's exponent byte.
+// Returns true when `n` holds the decoded normal (the set), false when the caller decodes t1 itself.
 template <int FS>
-TR_HD void fetch_texels(const DevTextures &tex, float u, float v, uint32_t &err, uint32_t &t0, uint32_t &t1, uint32_t &t2)
+TR_HD bool fetch_texels(const DevTextures &tex, float u, float v, uint32_t &err, uint32_t &t0, uint32_t &t1, uint32_t &t2, vec3 &n)
 {
     constexpr int K = packed_words(FS);
     t1 = t2 = 0u;
@@ -463,30 +472,19 @@ TR_HD void fetch_texels(const DevTextures &tex, float u, float v, uint32_t &err,
         const uint32_t at = packed_index(K, tex.packed_bpr, cx, cy);
         if (K == 1) {
             t0 = tex.packed[at];
-        } else if (K == 2) {
-            const Texel2 q = reinterpret_cast<const Texel2 *>(tex.packed)[at];
-            t0 = q.x;
-            t1 = q.y;
-        } else {
-            const Texel4 q = reinterpret_cast<const Texel4 *>(tex.packed)[at];
-            t0 = q.x;
-            t1 = q.y;
-            t2 = q.z;
+            return false;
         }
-        return;
+        const Texel4 q = reinterpret_cast<const Texel4 *>(tex.packed)[at];
+        t0 = q.x & 0xFFFFFFu;
+        t2 = q.x >> 24;
+        n = make3(bits_f32(q.y), bits_f32(q.z), bits_f32(q.w));
+        return true;
     }
     t0 = fetch_texel(tex, 0, 0, u, v, err);
     if (FS == FS_NORMAL_MAP || FS == FS_SPECULAR) t1 = fetch_texel(tex, 1, 1, u, v, err);
     if (FS == FS_DARBOUX) t1 = fetch_texel(tex, 2, 1, u, v, err);
-    if (FS == FS_SPECULAR) t2 = fetch_texel(tex, 3, 3, u, v, err);
-}
-
-// util.rs:51-56
-TR_HD vec3 decode_normal(uint32_t px)
-{
-    vec3 n = make3((float)(px & 0xFFu) / 255.0f - 0.5f, (float)((px >> 8) & 0xFFu) / 255.0f - 0.5f,
-                   (float)((px >> 16) & 0xFFu) / 255.0f - 0.5f);
-    return normalize3(n);
+    if (FS == FS_SPECULAR) t2 = fetch_texel(tex, 3, 3, u, v, err) & 0xFFu;
+    return false;
 }
 
 TR_HD uint32_t pack_rgb(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
@@ -546,23 +544,24 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
     vec3 tl = make3(u.t_light[0], u.t_light[1], u.t_light[2]);
 
     uint32_t c, t1, t2;  // the closure's texels (fetch_texels)
+    vec3 nd = make3(0.0f, 0.0f, 0.0f);
     if (FS == FS_DEFAULT) {
-        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2);
+        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
         return shade_blend(c, vary[6]);
     }
     if (FS == FS_PHONG) {
-        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2);
+        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
         float diff = dot3(bar, make3(vary[6], vary[7], vary[8]));
         return shade_blend(c, diff);
     }
     if (FS == FS_NORMAL_MAP) {
-        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2);
-        vec3 tn = transform_normal(u.it_m, decode_normal(t1));
+        const bool decoded = fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
+        vec3 tn = transform_normal(u.it_m, decoded ? nd : decode_normal(t1));
         return shade_blend(c, dot3(tl, tn));
     }
     if (FS == FS_SPECULAR) {
-        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2);
-        vec3 tn = transform_normal(u.it_m, decode_normal(t1));
+        const bool decoded = fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
+        vec3 tn = transform_normal(u.it_m, decoded ? nd : decode_normal(t1));
         // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
         vec3 a = scale3(tn, dot3(tl, tn));
         vec3 refl = normalize3(sub3(make3(2.0f * a.x, 2.0f * a.y, 2.0f * a.z), tl));
@@ -575,8 +574,8 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
                         f32_to_u8(fminf(k * (float)((c >> 16) & 0xFFu), 255.0f)));
     }
     if (FS == FS_DARBOUX) {
-        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2);
-        vec3 nt = decode_normal(t1);
+        const bool decoded = fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
+        vec3 nt = decoded ? nd : decode_normal(t1);
         vec3 n0 = make3(vary[12], vary[13], vary[14]);
         vec3 n1 = make3(vary[15], vary[16], vary[17]);
         vec3 n2 = make3(vary[18], vary[19], vary[20]);
@@ -615,7 +614,7 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
         float sv = shadow_fetch(shadow, sclean, W, H, sc, err);
         float coef = 1.0f;
         if (sc.z + 1.0f < sv) coef = 0.3f;
-        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2);
+        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
         float diff = dot3(bar, make3(vary[6], vary[7], vary[8]));
         return shade_blend(c, diff * coef);
     }
@@ -799,15 +798,18 @@ TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, con
     const vec3p tl = splat3p(make3(u.t_light[0], u.t_light[1], u.t_light[2]));
     PairGuard g = guard_init();
     uint32_t ta, ta1, ta2, tb, tb1, tb2;  // the closure's texels at both pixels (fetch_texels)
-    fetch_texels<FS>(tex, uu.x, vv.x, ea, ta, ta1, ta2);
-    fetch_texels<FS>(tex, uu.y, vv.y, eb, tb, tb1, tb2);
+    vec3 na = make3(0.0f, 0.0f, 0.0f), nb = na;
+    const bool decoded = fetch_texels<FS>(tex, uu.x, vv.x, ea, ta, ta1, ta2, na);
+    fetch_texels<FS>(tex, uu.y, vv.y, eb, tb, tb1, tb2, nb);
+    // the normal the closure decodes from its normal map: from the texel set, or decoded here (plain images)
+    const vec3p nrm = decoded ? make3p(mk2(na.x, nb.x), mk2(na.y, nb.y), mk2(na.z, nb.z)) : decode_normal_p(ta1, tb1);
     f2 result;  // the value whose NaN-ness decides (every fast operation feeds it)
     if (FS == FS_NORMAL_MAP) {
-        const vec3p tn = transform_normal_p(u.it_m, decode_normal_p(ta1, tb1), g);
+        const vec3p tn = transform_normal_p(u.it_m, nrm, g);
         result = dot3p(tl, tn);
         shade_blend_p(ta, tb, result, ca, cb);
     } else if (FS == FS_SPECULAR) {
-        const vec3p tn = transform_normal_p(u.it_m, decode_normal_p(ta1, tb1), g);
+        const vec3p tn = transform_normal_p(u.it_m, nrm, g);
         // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
         const f2 d0 = dot3p(tl, tn);
         const f2 two = splat2(2.0f);
@@ -824,7 +826,7 @@ TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, con
             cb |= f32_to_u8(fminf(v.y, 255.0f)) << (8 * ch);
         }
     } else {  // FS_DARBOUX
-        const vec3p nt = decode_normal_p(ta1, tb1);
+        const vec3p nt = nrm;
         const vec3p local_z = mul_m3_v3p(make3p(vary(12), vary(13), vary(14)), make3p(vary(15), vary(16), vary(17)),
                                          make3p(vary(18), vary(19), vary(20)), bar);
         const vec3p r2 = normalize3p(local_z, g);
@@ -861,4 +863,31 @@ TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, con
     bad_b = guard_bad(g, 1) || !(result.y == result.y);
 }
 
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace tr
+#include <vector>
+namespace tr {
+// Host: the texel set of closure `fs` (tr_texels.h) from the four rgba8 images (all w x h); `bpr` receives the blocks
+// per row.  The normals are decode_normal's -- the function the closures call when there is no set.
+inline std::vector<uint32_t> pack_texels(int fs, const uint32_t *const image[4], uint32_t w, uint32_t h, uint32_t &bpr)
+{
+    const int K = packed_words(fs), lbw = packed_lbw(K), lbh = packed_lbh(K), nsrc = packed_normal_source(fs);
+    bpr = (w + (1u << lbw) - 1u) >> lbw;
+    const uint32_t rows = (h + (1u << lbh) - 1u) >> lbh;
+    std::vector<uint32_t> packed(((size_t)bpr * rows << (lbw + lbh)) * K, 0u);
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const size_t at = (size_t)packed_index(K, bpr, x, y) * K, i = (size_t)y * w + x;
+            packed[at] = (image[0][i] & 0xFFFFFFu) | (fs == FS_SPECULAR ? (image[3][i] & 0xFFu) << 24 : 0u);
+            if (K == 4) {
+                const vec3 n = decode_normal(image[nsrc][i]);
+                packed[at + 1] = f32_bits(n.x);
+                packed[at + 2] = f32_bits(n.y);
+                packed[at + 3] = f32_bits(n.z);
+            }
+        }
+    return packed;
+}
+#endif
 }  // namespace tr
