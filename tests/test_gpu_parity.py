@@ -408,6 +408,56 @@ def test_baseline_configs_at_full_size(diablo, cfg):
     gpu.close()
 
 
+@pytest.mark.parametrize("pipe", ["normal_map", "specular"])
+def test_lit_texel_path_on_small_frames(synthetic, pipe, monkeypatch):
+    """The normal-map and specular closures are functions of the texel alone, so a scene whose frame has many more pixels
+    than its images have texels runs them ONCE PER TEXEL and frame (k_lit) and lets the fragment stage fetch the result
+    (FS_LIT) -- by default from sixteen pixels per texel (4096^2 frames of the reference's 1024^2 images:
+    test_baseline_configs_at_full_size covers the x64 grid at 8192^2).  Forced here on a small frame, whose images are
+    also not a multiple of the 8x4 / 4x2 blocks: single frames with a moving camera and light, an accumulating render,
+    and a group call, all against the oracle; and the kernel really runs."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    monkeypatch.setenv("TR_LIT", "1")
+    mesh, texs = synthetic
+    texs = [np.ascontiguousarray(t[:250, :203]) for t in texs]
+    W, Hh = 520, 390
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, winner_tap=True)
+    cpu = O.Scene(W, Hh, mesh, texs, pipe)
+    gpu.profile_enable(True)
+    for i, (ca, la, clear) in enumerate([(0.3, 0.2, True), (1.4, -0.6, True), (2.0, 0.9, False), (0.1, 2.2, True)]):
+        for s_ in (gpu, cpu):
+            if clear:
+                s_.clear()
+            s_.set_light_direction(H.light(la))
+            s_.set_camera(*H.camera(ca))
+        assert cpu.render() == 0
+        gpu.render()
+        assert_parity(gpu, cpu, pipe)
+    assert gpu.profile_read()["k_lit"]["launches"] == 4
+    gpu.close()
+    # a group call (no winner tap: the fused launches)
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, frames_per_launch=4)
+    p = np.zeros((6, 12), np.float32)
+    for i in range(6):
+        p[i, 0:3] = H.light(0.4 * i - 1.0)
+        f, a, u = H.camera(0.7 * i)
+        p[i, 3:6], p[i, 6:9], p[i, 9:12] = f, a, u
+    gpu.render_frames(p)
+    for back in range(gpu.frames_kept()):
+        gpu.select_frame(back)
+        q = p[5 - back]
+        cpu.clear(); cpu.set_light_direction(q[0:3]); cpu.set_camera(q[3:6], q[6:9], q[9:12])
+        assert cpu.render() == 0
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
+        fg, fo = gpu.get_frame_buffer(), cpu.get_frame_buffer()
+        if pipe in EXACT or specular_exact():
+            assert np.array_equal(fg, fo), "frame -%d" % back
+        else:
+            assert np.abs(fg.astype(np.int32) - fo.astype(np.int32)).max() <= 1  # tolerance: 1 LSB (device powf)
+    gpu.close()
+
+
 @pytest.mark.parametrize("pipe", ["phong", "shadow"])
 def test_bin_overflow_grows_and_rerenders(synthetic, pipe):
     """More (polygon, tile) pairs in a pass than the record pool holds (a pool of 64, far below the automatic

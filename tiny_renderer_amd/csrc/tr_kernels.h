@@ -23,6 +23,8 @@ namespace tr {
 // running beside a tile kernel).
 int launch_setup(int vs_kind, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bool hurry, hipStream_t st,
                  hipEvent_t start, hipEvent_t done);
+// The frame's lit texel image (k_lit: the normal-map / specular closure once per texel); a.lit, a.texel_set etc. say where.
+int launch_lit(int fs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done);
 // Builds the tile kernel's work lists from the counters k_setup filled (same stream, after it) and gives every tile
 // its range of the pool.  `one`: the pass's arguments (a per-frame launch); `group`: the fused launch's table.
 int launch_order(const TileArgs &one, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start,

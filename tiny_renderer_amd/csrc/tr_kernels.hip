@@ -253,6 +253,40 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_bin_group(const SetupArgs *__
 }
 
 // -----------------------------------------------------------------------------------------
+// k_lit
+// -----------------------------------------------------------------------------------------
+// The normal-map and specular closures use nothing of a fragment but its texel (shade_texel, tr_shaders.h): under one
+// frame's light and camera the colour of a fragment is a function of (u, v)'s texel alone.  Where a frame shades many
+// more fragments than the images have texels -- the x64 grid at 8192^2: ~20 M fragments, 1 M texels -- the closure
+// runs ONCE PER TEXEL here, in the chain in front of the tile kernel, and the tile kernel's fragment stage is a fetch
+// from the frame's lit image (FS_LIT).  The arithmetic is the plain closure's (IEEE division and square root, the
+// exact powf): what a fragment finds is what it would have computed.  Thread = texel of the scene's texel set
+// (four-word texels in 4x2 blocks); the lit image is a one-word image in 8x4 blocks (tr_texels.h).
+template <int FS>
+__device__ __forceinline__ void lit_body(const SetupArgs &a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t block = i >> 3, within = i & 7u;
+    const uint32_t x = (block % a.set_bpr) * 4u + (within & 3u), y = (block / a.set_bpr) * 2u + (within >> 2);
+    if (x >= a.tex_w || y >= a.tex_h) return;
+    const Texel4 q = reinterpret_cast<const Texel4 *>(a.texel_set)[i];
+    const uint32_t c = shade_texel<FS>(a.u, q.x & 0xFFFFFFu, make3(bits_f32(q.y), bits_f32(q.z), bits_f32(q.w)), q.x >> 24);
+    a.lit[packed_index(1, a.lit_bpr, x, y)] = c;
+}
+
+template <int FS>
+__global__ __launch_bounds__(256) void k_lit(SetupArgs a)
+{
+    lit_body<FS>(a);
+}
+
+template <int FS>
+__global__ __launch_bounds__(256) void k_lit_group(const SetupArgs *__restrict__ table)
+{
+    lit_body<FS>(table[blockIdx.y]);
+}
+
+// -----------------------------------------------------------------------------------------
 // k_order
 // -----------------------------------------------------------------------------------------
 // Turns the per-tile polygon counts k_setup left into the tile kernel's WORK LISTS: every tile once, as
@@ -1045,7 +1079,13 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
             uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
             vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
-            if (FS == FS_DEFAULT || FS == FS_PHONG) {
+            if (FS == FS_LIT) {
+                // the frame's lit texel image (k_lit): the closure has run for this texel already
+                uint32_t unused1, unused2;
+                vec3 unused3;
+                fetch_texels<FS>(a.tex, uu.x, vv.x, ea, ca, unused1, unused2, unused3);
+                fetch_texels<FS>(a.tex, uu.y, vv.y, eb, cb, unused1, unused2, unused3);
+            } else if (FS == FS_DEFAULT || FS == FS_PHONG) {
                 // shader.rs:318-333 / 386-401 for both pixels at once: texel, diffuse term,
                 // color_blend(c, 0, t) = (t * c + (1 - t) * 0.0) as u8 per channel
                 uint32_t ta, tb, unused1, unused2;
@@ -1557,6 +1597,26 @@ int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bo
     return 0;
 }
 
+int launch_lit(int fs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done)
+{
+    if (!a.lit || !a.texel_set || a.tex_w == 0 || a.tex_h == 0) return (int)hipErrorInvalidValue;
+    if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
+    const uint32_t rows = (a.tex_h + 1u) / 2u;
+    const uint64_t texels = (uint64_t)a.set_bpr * rows * 8u;
+    const dim3 grid((uint32_t)((texels + 255u) / 256u), group ? n_frames : 1u), block(256);
+    if (fs == FS_SPECULAR) {
+        if (group) hipExtLaunchKernelGGL(k_lit_group<FS_SPECULAR>, grid, block, 0, st, start, done, 0, group);
+        else hipExtLaunchKernelGGL(k_lit<FS_SPECULAR>, grid, block, 0, st, start, done, 0, a);
+    } else if (fs == FS_NORMAL_MAP) {
+        if (group) hipExtLaunchKernelGGL(k_lit_group<FS_NORMAL_MAP>, grid, block, 0, st, start, done, 0, group);
+        else hipExtLaunchKernelGGL(k_lit<FS_NORMAL_MAP>, grid, block, 0, st, start, done, 0, a);
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+    TR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_order(const TileArgs &one, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames, hipStream_t st, hipEvent_t start,
                  hipEvent_t done)
 {
@@ -1591,6 +1651,7 @@ static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const 
     TR_TILE_CASE(FS_SHADOW2)
     TR_TILE_CASE(FS_OCCLUSION2)
     TR_TILE_CASE(FS_DEPTH)
+    TR_TILE_CASE(FS_LIT)
     default: return (int)hipErrorInvalidValue;
     }
 #undef TR_TILE_CASE

@@ -533,6 +533,28 @@ TR_HD float shadow_fetch(const float *shadow, const uint32_t *sclean, uint32_t W
 }
 
 // Runs fragment closure `FS` for a fragment whose depth test has already passed.
+// The normal-map and specular closures after their texel fetches (shader.rs:439-459, 498-534): colour texel `c`, the
+// normal decoded from the normal map's texel, the specular map's exponent byte.  Nothing else enters them but the
+// frame's constants: the colour is a function of the TEXEL -- which is what lets k_lit run them once per texel and
+// frame instead of once per fragment.
+template <int FS>
+TR_HD uint32_t shade_texel(const DevUniforms &u, uint32_t c, vec3 n, uint32_t exponent)
+{
+    const vec3 tl = make3(u.t_light[0], u.t_light[1], u.t_light[2]);
+    const vec3 tn = transform_normal(u.it_m, n);
+    if (FS == FS_NORMAL_MAP) return shade_blend(c, dot3(tl, tn));
+    // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
+    vec3 a = scale3(tn, dot3(tl, tn));
+    vec3 refl = normalize3(sub3(make3(2.0f * a.x, 2.0f * a.y, 2.0f * a.z), tl));
+    float diff = dot3(tl, tn);
+    float e = (float)(exponent & 0xFFu);
+    float spec = 0.6f * tr_powf(fmaxf(refl.z, 0.0f), e);  // the host libm's powf, bit for bit (tr_powf.h)
+    float k = diff + spec;
+    return pack_rgb(f32_to_u8(fminf(k * (float)(c & 0xFFu), 255.0f)),
+                    f32_to_u8(fminf(k * (float)((c >> 8) & 0xFFu), 255.0f)),
+                    f32_to_u8(fminf(k * (float)((c >> 16) & 0xFFu), 255.0f)));
+}
+
 // Returns packed rgb (r | g<<8 | b<<16).
 // The part of fragment closure `FS` after `uv = vertex_uvs * bar`: texel fetches, lighting, blend.
 template <int FS>
@@ -556,22 +578,15 @@ TR_HD uint32_t fragment_color(const DevUniforms &u, const DevTextures &tex, cons
     }
     if (FS == FS_NORMAL_MAP) {
         const bool decoded = fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
-        vec3 tn = transform_normal(u.it_m, decoded ? nd : decode_normal(t1));
-        return shade_blend(c, dot3(tl, tn));
+        return shade_texel<FS>(u, c, decoded ? nd : decode_normal(t1), t2);
+    }
+    if (FS == FS_LIT) {  // the closure has run for this texel already (k_lit)
+        fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
+        return c;
     }
     if (FS == FS_SPECULAR) {
         const bool decoded = fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);
-        vec3 tn = transform_normal(u.it_m, decoded ? nd : decode_normal(t1));
-        // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
-        vec3 a = scale3(tn, dot3(tl, tn));
-        vec3 refl = normalize3(sub3(make3(2.0f * a.x, 2.0f * a.y, 2.0f * a.z), tl));
-        float diff = dot3(tl, tn);
-        float e = (float)(t2 & 0xFFu);
-        float spec = 0.6f * tr_powf(fmaxf(refl.z, 0.0f), e);  // the host libm's powf, bit for bit (tr_powf.h)
-        float k = diff + spec;
-        return pack_rgb(f32_to_u8(fminf(k * (float)(c & 0xFFu), 255.0f)),
-                        f32_to_u8(fminf(k * (float)((c >> 8) & 0xFFu), 255.0f)),
-                        f32_to_u8(fminf(k * (float)((c >> 16) & 0xFFu), 255.0f)));
+        return shade_texel<FS>(u, c, decoded ? nd : decode_normal(t1), t2);
     }
     if (FS == FS_DARBOUX) {
         const bool decoded = fetch_texels<FS>(tex, uu, vv, err, c, t1, t2, nd);

@@ -37,6 +37,7 @@ enum FsKind : int {
     FS_SHADOW2,      // shader.rs:749-788
     FS_OCCLUSION2,   // shader.rs:872-947
     FS_DEPTH,        // shader.rs:694-709, 832-847 (shadow-buffer fill, draws nothing)
+    FS_LIT,          // the colour of the frame's lit texel image at (u, v) (k_lit: normal-map / specular closures once per texel)
     FS_COUNT
 };
 
@@ -184,6 +185,11 @@ struct SetupArgs {
     // 1: the tile kernel resolves small pairs as scan-line items (shared form): they get cell masks; 0: every pair
     // gets the block columns (pair_masks, tr_shaders.h)
     uint32_t cells;
+    // the frame's lit texel image (k_lit; null: the closure runs per fragment): colour of every texel under this frame's
+    // light and camera, from the scene's texel set `texel_set` (tex_w x tex_h texels, set_bpr / lit_bpr blocks per row)
+    uint32_t *lit;
+    const uint32_t *texel_set;
+    uint32_t tex_w, tex_h, set_bpr, lit_bpr;
 };
 
 struct TileArgs {
