@@ -36,7 +36,7 @@ def one(pattern):
 def kernel_of(name):
     if "k_tile" in name:
         return "k_tile_depth" if "<7," in name.replace(" ", "") or "FS_DEPTH" in name else "k_tile"
-    for k in ("k_setup", "k_order", "k_bin", "k_read_back", "k_push_tiles", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
+    for k in ("k_setup", "k_order", "k_bin", "k_lit", "k_read_back", "k_push_tiles", "k_materialize_depth", "k_fill_u32", "k_depth_view"):
         if k in name:
             return k
     return name[:48]
