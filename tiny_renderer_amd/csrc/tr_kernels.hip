@@ -259,19 +259,31 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_bin_group(const SetupArgs *__
 // frame's light and camera the colour of a fragment is a function of (u, v)'s texel alone.  Where a frame shades many
 // more fragments than the images have texels -- the x64 grid at 8192^2: ~20 M fragments, 1 M texels -- the closure
 // runs ONCE PER TEXEL here, in the chain in front of the tile kernel, and the tile kernel's fragment stage is a fetch
-// from the frame's lit image (FS_LIT).  The arithmetic is the plain closure's (IEEE division and square root, the
-// exact powf): what a fragment finds is what it would have computed.  Thread = texel of the scene's texel set
-// (four-word texels in 4x2 blocks); the lit image is a one-word image in 8x4 blocks (tr_texels.h).
+// from the frame's lit image (FS_LIT).  The arithmetic is the fragment stage's own -- the two-texel closure with its
+// guard, the plain closure (IEEE division and square root) behind it, the exact powf: what a fragment finds is what it
+// would have computed.  Thread = two texels of the scene's texel set (four-word texels in 4x2 blocks); the lit image is
+// a one-word image in 8x4 blocks (tr_texels.h).
 template <int FS>
 __device__ __forceinline__ void lit_body(const SetupArgs &a)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    // two texels per thread -- neighbours in a row of a 4x2 block -- through the two-texel closure (packed arithmetic,
+    // shared-reciprocal divisions: shade_texel_pair); a texel that leaves its guarded range is redone by the plain one
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 2u;
     const uint32_t block = i >> 3, within = i & 7u;
     const uint32_t x = (block % a.set_bpr) * 4u + (within & 3u), y = (block / a.set_bpr) * 2u + (within >> 2);
     if (x >= a.tex_w || y >= a.tex_h) return;
-    const Texel4 q = reinterpret_cast<const Texel4 *>(a.texel_set)[i];
-    const uint32_t c = shade_texel<FS>(a.u, q.x & 0xFFFFFFu, make3(bits_f32(q.y), bits_f32(q.z), bits_f32(q.w)), q.x >> 24);
-    a.lit[packed_index(1, a.lit_bpr, x, y)] = c;
+    const bool second = x + 1u < a.tex_w;
+    const Texel4 q0 = reinterpret_cast<const Texel4 *>(a.texel_set)[i], q1 = reinterpret_cast<const Texel4 *>(a.texel_set)[i + 1u];
+    const vec3 n0 = make3(bits_f32(q0.y), bits_f32(q0.z), bits_f32(q0.w)), n1 = make3(bits_f32(q1.y), bits_f32(q1.z), bits_f32(q1.w));
+    PairGuard g = guard_init();
+    uint32_t c0 = 0u, c1 = 0u;
+    const f2 r = shade_texel_pair<FS>(a.u, q0.x & 0xFFFFFFu, q1.x & 0xFFFFFFu, make3p(mk2(n0.x, n1.x), mk2(n0.y, n1.y), mk2(n0.z, n1.z)),
+                                      q0.x >> 24, q1.x >> 24, g, c0, c1);
+    if (guard_bad(g, 0) || !(r.x == r.x)) c0 = shade_texel<FS>(a.u, q0.x & 0xFFFFFFu, n0, q0.x >> 24);
+    if (second && (guard_bad(g, 1) || !(r.y == r.y))) c1 = shade_texel<FS>(a.u, q1.x & 0xFFFFFFu, n1, q1.x >> 24);
+    const uint32_t at = packed_index(1, a.lit_bpr, x, y);  // (x even: x + 1 is the next texel of the same 8x4 block row)
+    a.lit[at] = c0;
+    if (second) a.lit[at + 1u] = c1;
 }
 
 template <int FS>
@@ -1603,7 +1615,7 @@ int launch_lit(int fs, const SetupArgs &a, const SetupArgs *group, uint32_t n_fr
     if (group && (n_frames == 0 || n_frames > 65535u)) return (int)hipErrorInvalidValue;
     const uint32_t rows = (a.tex_h + 1u) / 2u;
     const uint64_t texels = (uint64_t)a.set_bpr * rows * 8u;
-    const dim3 grid((uint32_t)((texels + 255u) / 256u), group ? n_frames : 1u), block(256);
+    const dim3 grid((uint32_t)((texels / 2u + 255u) / 256u), group ? n_frames : 1u), block(256);  // (two texels per thread)
     if (fs == FS_SPECULAR) {
         if (group) hipExtLaunchKernelGGL(k_lit_group<FS_SPECULAR>, grid, block, 0, st, start, done, 0, group);
         else hipExtLaunchKernelGGL(k_lit<FS_SPECULAR>, grid, block, 0, st, start, done, 0, a);

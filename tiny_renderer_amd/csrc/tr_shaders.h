@@ -802,6 +802,39 @@ constexpr bool has_pair_closure(int fs)
     return (fs == FS_NORMAL_MAP || fs == FS_SPECULAR || fs == FS_DARBOUX) && ((TR_PAIR_CLOSURES >> fs) & 1);
 }
 
+// shade_texel for two texels at once in the packed forms (normal-map and specular closures): colour texels ta / tb, the
+// decoded normals, the exponent bytes.  Returns the value whose NaN-ness -- with the guard -- tells whether a texel must
+// be redone by the plain closure; used by the two-pixel fragment closure and by k_lit.
+template <int FS>
+TR_HD f2 shade_texel_pair(const DevUniforms &u, uint32_t ta, uint32_t tb, vec3p nrm, uint32_t ea_byte, uint32_t eb_byte,
+                          PairGuard &g, uint32_t &ca, uint32_t &cb)
+{
+    const vec3p tl = splat3p(make3(u.t_light[0], u.t_light[1], u.t_light[2]));
+    const vec3p tn = transform_normal_p(u.it_m, nrm, g);
+    f2 result;
+    if (FS == FS_NORMAL_MAP) {
+        result = dot3p(tl, tn);
+        shade_blend_p(ta, tb, result, ca, cb);
+    } else {
+        // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
+        const f2 d0 = dot3p(tl, tn);
+        const f2 two = splat2(2.0f);
+        const vec3p refl = normalize3p(make3p(two * (tn.x * d0) - tl.x, two * (tn.y * d0) - tl.y, two * (tn.z * d0) - tl.z), g);
+        const f2 diff = dot3p(tl, tn);
+        const float e0 = (float)(ea_byte & 0xFFu), e1 = (float)(eb_byte & 0xFFu);
+        const f2 spec = splat2(0.6f) * mk2(tr_powf(fmaxf(refl.z.x, 0.0f), e0), tr_powf(fmaxf(refl.z.y, 0.0f), e1));
+        result = diff + spec;
+        ca = 0u;
+        cb = 0u;
+        for (int ch = 0; ch < 3; ch++) {
+            const f2 v = result * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu));
+            ca |= f32_to_u8(fminf(v.x, 255.0f)) << (8 * ch);
+            cb |= f32_to_u8(fminf(v.y, 255.0f)) << (8 * ch);
+        }
+    }
+    return result;
+}
+
 // The part of fragment closure `FS` after `uv = vertex_uvs * bar` for two pixels (possibly of
 // different polygons): `vary(k)` returns varying k of both.  bad_a / bad_b: that pixel left the
 // guarded range -- its colour must come from fragment_color<FS> instead (error bits too: the fast
@@ -819,27 +852,8 @@ TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, con
     // the normal the closure decodes from its normal map: from the texel set, or decoded here (plain images)
     const vec3p nrm = decoded ? make3p(mk2(na.x, nb.x), mk2(na.y, nb.y), mk2(na.z, nb.z)) : decode_normal_p(ta1, tb1);
     f2 result;  // the value whose NaN-ness decides (every fast operation feeds it)
-    if (FS == FS_NORMAL_MAP) {
-        const vec3p tn = transform_normal_p(u.it_m, nrm, g);
-        result = dot3p(tl, tn);
-        shade_blend_p(ta, tb, result, ca, cb);
-    } else if (FS == FS_SPECULAR) {
-        const vec3p tn = transform_normal_p(u.it_m, nrm, g);
-        // (2.0 * (t_n * t_light.dot(t_n)) - t_light).normalize(), shader.rs:515-518
-        const f2 d0 = dot3p(tl, tn);
-        const f2 two = splat2(2.0f);
-        const vec3p refl = normalize3p(make3p(two * (tn.x * d0) - tl.x, two * (tn.y * d0) - tl.y, two * (tn.z * d0) - tl.z), g);
-        const f2 diff = dot3p(tl, tn);
-        const float e0 = (float)(ta2 & 0xFFu), e1 = (float)(tb2 & 0xFFu);
-        const f2 spec = splat2(0.6f) * mk2(tr_powf(fmaxf(refl.z.x, 0.0f), e0), tr_powf(fmaxf(refl.z.y, 0.0f), e1));
-        result = diff + spec;
-        ca = 0u;
-        cb = 0u;
-        for (int ch = 0; ch < 3; ch++) {
-            const f2 v = result * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu));
-            ca |= f32_to_u8(fminf(v.x, 255.0f)) << (8 * ch);
-            cb |= f32_to_u8(fminf(v.y, 255.0f)) << (8 * ch);
-        }
+    if (FS == FS_NORMAL_MAP || FS == FS_SPECULAR) {
+        result = shade_texel_pair<FS>(u, ta, tb, nrm, ta2, tb2, g, ca, cb);
     } else {  // FS_DARBOUX
         const vec3p nt = nrm;
         const vec3p local_z = mul_m3_v3p(make3p(vary(12), vary(13), vary(14)), make3p(vary(15), vary(16), vary(17)),
