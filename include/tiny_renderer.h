@@ -24,6 +24,11 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: what this header declares is all it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #define TR_ABI_VERSION 2
 
 /* Status codes.  0 = ok, negative = failure (the reference panics at the cited site). */
@@ -89,9 +94,11 @@ typedef struct tr_options {
     void *frame_buffer_device; /* device pointer to 3*W*H bytes to render into (e.g. the
                                   all-gather buffer); NULL = library-owned */
     uint64_t bin_capacity;     /* records in a pass's pool = (polygon, 128x16 screen tile) pairs of one pass of one
-                                  frame; every tile gets exactly the records it needs from it.  0 = automatic
-                                  (8 per polygon, at least 65 536).  A pass that needs more grows the pools and
-                                  the frame is rendered again. */
+                                  frame; every tile gets exactly the records it needs from it.  0 = automatic:
+                                  twice an estimate from the frame size and the polygon count -- polygons with
+                                  boxes of side s = sqrt(2 W H / n) meet (1 + s/128)(1 + s/16) tiles each, half
+                                  of them face the viewer -- at least 65 536 and at most 16 Mi records.  A pass
+                                  that needs more grows the pools and the frame is rendered again. */
     uint32_t tile_waves;       /* wavefronts per 128x16 screen tile: 4, 8, 16, or 0 = automatic (more
                                   while the tiles cannot fill the GPU, 4 from 4096x4096 up).
                                   Speed only: results do not depend on it. */
@@ -103,6 +110,11 @@ typedef struct tr_options {
                                   automatic (by tile count: 4 at 4096x4096, 32 for small frames; a call of several
                                   groups uses up to three times that per launch, a call of sixteen groups or more
                                   grows to 32).  Speed only. */
+    uint32_t max_frame_slots;  /* upper bound on the scene's frame slots -- complete sets of render targets (z,
+                                  colour, shadow buffer: 7 to 11 bytes per pixel each), one per frame of a group in
+                                  flight, hence also on the frames per launch: 1..32, 0 = automatic (as many as the
+                                  largest group, up to 32 within 8 GiB; a device without room for that falls back to
+                                  the usual group by itself).  For callers that keep many scenes on one GPU. */
 } tr_options;
 
 typedef struct tr_scene tr_scene;
@@ -175,9 +187,11 @@ int tr_scene_read_winner_u32(tr_scene *s, uint32_t *out); /* needs TR_OPT_WINNER
  * knows which 128x16 tiles of the frame hold the cleared colour, and remembers per host buffer which tiles it
  * has written as zeros there -- those are skipped (widths that are multiples of 16; three quarters of a
  * 4096x4096 frame of the reference's model: 1.1 ms -> 0.3 ms per frame).  The buffer always ends up holding the
- * complete frame.  A caller that WRITES into such a buffer between two read-backs says so with
- * tr_scene_host_buffer_written (the scene then assumes nothing about its content); reading it needs nothing.
- * Any other host memory receives the whole frame through the copy engine. */
+ * complete frame: the record of a buffer's zero tiles belongs to the scene that wrote it last and lapses when
+ * anybody else writes the buffer -- another scene reading back into it (the library knows), or the caller, who
+ * says so with tr_scene_host_buffer_written (no scene then assumes anything about its content); reading it needs
+ * nothing.  A band scene (tr_options.band_row0/1) and any other host memory receive the whole frame buffer through
+ * the copy engine. */
 int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb);
 void *tr_host_alloc(size_t bytes); /* page-locked host memory mapped into the device, NULL on failure */
 void tr_host_free(void *p);
@@ -342,6 +356,10 @@ int tr_save_png_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t 
 
 const char *tr_last_error(void);
 int tr_abi_version(void);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -292,6 +292,83 @@ def test_sparse_read_back_orbit(diablo):
     gpu.close()
 
 
+def test_band_scene_reads_back_the_whole_buffer(small_synthetic):
+    """A band scene (tr_options.band_row0/1) renders some rows of a frame buffer whose other rows belong to somebody
+    else (other ranks' bands in an all-gather buffer).  tr_scene_get_frame_buffer_async into page-locked memory must
+    deliver the COMPLETE buffer -- what tr_scene_get_frame_buffer returns -- not only the band's tiles: the sparse
+    tile path is for scenes that render the whole frame."""
+    import torch
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W, Hh = 512, 256
+    full = torch.full((Hh * W * 3,), 7, dtype=torch.uint8, device="cuda")   # "other ranks' rows": sevens
+    torch.cuda.synchronize()
+    gpu = T.Scene(W, Hh, mesh, texs, "phong", band_rows=(64, 176), frame_buffer_device=full.data_ptr())
+    pinned = gpu.pinned_frame()
+    for k in range(3):
+        pinned[...] = 0xAB                            # garbage the read-back must replace everywhere
+        gpu.clear(), gpu.set_light_direction(H.light(0.2)), gpu.set_camera(*H.camera(0.4 * k)), gpu.render()
+        gpu.get_frame_buffer_async(pinned)
+        assert gpu.sync() == 0
+        want = gpu.get_frame_buffer()
+        assert (want[:64] == 7).all() and (want[176:] == 7).all() and want[64:176].any()
+        assert np.array_equal(pinned, want), "read-back %d" % k
+    gpu.close()
+
+
+def test_two_scenes_share_one_pinned_buffer(small_synthetic):
+    """The record of which tiles of a page-locked buffer hold zeros belongs to the scene that wrote the buffer last:
+    when another scene has read back into the same buffer in between, nothing may be skipped."""
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W, Hh = 1024, 512
+    a = T.Scene(W, Hh, mesh, texs, "phong")
+    # the second scene's model fills tiles the first one leaves empty (the same sphere, off to the right)
+    moved = dict(mesh)
+    moved["pos"] = (mesh["pos"] * np.float32(0.5) + np.array([0.45, 0.3, 0.0], np.float32)).astype(np.float32)
+    b = T.Scene(W, Hh, moved, texs, "default")
+    pinned = a.pinned_frame()
+    frames = {}
+    for name, s in (("a", a), ("b", b)):
+        s.clear(), s.set_light_direction(H.light(0.1)), s.set_camera(*H.camera(0.0)), s.render()
+        frames[name] = s.get_frame_buffer()
+    assert (frames["b"].any(-1) & ~frames["a"].any(-1)).sum() > 1000    # b lights pixels a leaves black
+    for k, (name, s) in enumerate((("a", a), ("b", b), ("a", a), ("a", a), ("b", b), ("b", b), ("a", a))):
+        s.clear(), s.set_light_direction(H.light(0.1)), s.set_camera(*H.camera(0.0)), s.render()
+        s.get_frame_buffer_async(pinned)
+        assert s.sync() == 0
+        assert np.array_equal(pinned, frames[name]), "read-back %d (scene %s)" % (k, name)
+    b.close()
+    a.close()
+
+
+def test_max_frame_slots_bounds_the_groups(small_synthetic):
+    """tr_options.max_frame_slots caps the frame slots (and with them the frames per launch); results do not change."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh = 320, 200
+    for cap in (1, 3):
+        gpu = T.Scene(W, Hh, mesh, texs, "shadow", max_frame_slots=cap)
+        assert gpu.frames_per_launch == cap
+        frames = np.zeros((11, 12), np.float32)
+        for i in range(len(frames)):
+            frames[i, 0:3] = H.light(0.3 * i)
+            frames[i, 3:6], frames[i, 6:9], frames[i, 9:12] = H.camera(0.25 * i)
+        gpu.render_frames(frames)
+        assert gpu.frames_kept() == min(cap, len(frames))
+        cpu = O.Scene(W, Hh, mesh, texs, "shadow")
+        for back in range(gpu.frames_kept()):
+            q = frames[len(frames) - 1 - back]
+            cpu.clear(), cpu.set_light_direction(q[0:3]), cpu.set_camera(q[3:6], q[6:9], q[9:12]), cpu.render()
+            gpu.select_frame(back)
+            assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer()), (cap, back)
+        cpu.close()
+        gpu.close()
+    with pytest.raises(T.TinyRendererError):
+        T.Scene(W, Hh, mesh, texs, "phong", max_frame_slots=2, frames_per_launch=4)
+
+
 def test_depth_views(small_synthetic):
     """get_z_buffer / get_shadow_buffer (scene.rs:101-125)."""
     mesh, texs = small_synthetic

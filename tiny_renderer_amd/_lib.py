@@ -51,7 +51,8 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("band_row0", C.c_uint32), ("band_row1", C.c_uint32), ("stream", C.c_void_p),
                 ("frame_buffer_device", C.c_void_p), ("bin_capacity", C.c_uint64),
-                ("tile_waves", C.c_uint32), ("tile_mode", C.c_uint32), ("frames_per_launch", C.c_uint32)]
+                ("tile_waves", C.c_uint32), ("tile_mode", C.c_uint32), ("frames_per_launch", C.c_uint32),
+                ("max_frame_slots", C.c_uint32)]
 
 
 class FrameParams(C.Structure):

@@ -309,9 +309,10 @@ __global__ __launch_bounds__(256) void k_lit_group(const SetupArgs *__restrict__
 // front of every tile kernel.)  The tile kernel walks the lists heaviest first (longest-processing-time-first
 // packing) and handles the empty tiles in batches.  Inside a list the tiles come in a hashed order: tiles that
 // are neighbours on the screen cost about the same and read the same texture region -- in row-major order the
-// tile kernel was 15 % slower.  The kernel also zeroes the counters it has read (for the pass that uses the set
-// next); the 16 words behind them -- the list lengths -- are zeroed by k_setup's
-// first workgroup earlier in the same stream.
+// tile kernel was 15 % slower.  A tile's counter leaves this kernel as the END of the tile's range in the pool
+// (k_bin counts it down to the start; the tile's own k_tile workgroup zeroes it for the set's next pass); the 16
+// words behind the counters -- the list lengths, the pool cursor -- are zeroed by k_setup's first workgroup
+// earlier in the same stream.
 constexpr int ORDER_BUCKETS = 8;
 constexpr int ORDER_THREADS = 256;
 constexpr int ORDER_EMPTY = ORDER_BUCKETS - 1;  // the list of the tiles without polygons
@@ -340,7 +341,15 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t n)
 
 // `group` != null: blockIdx.y = frame of a group, whose counters, work lists and pool are in entry y of the tile
 // kernel's argument table; else `one` describes the pass.
-constexpr int ORDER_POOL = ORDER_BUCKETS;  // word behind the list lengths (per-frame sets) / in the set's words: the pool cursor
+// The pool cursor: a 64-bit word among the eight words behind the list lengths (at the first 8-byte boundary) -- the
+// pairs a pass WANTS may exceed 2^32 (a million polygons that each cross a large frame) even though no pool can
+// hold them: ranges are formed in 64 bits and saturate, so that "how many records the pass wanted" stays meaningful
+constexpr int ORDER_POOL = ORDER_BUCKETS;
+__device__ __forceinline__ unsigned long long *order_pool_cursor(uint32_t *words_behind_counters)
+{
+    return reinterpret_cast<unsigned long long *>(((uintptr_t)(words_behind_counters + ORDER_POOL) + 7u) & ~(uintptr_t)7u);
+}
+__device__ __forceinline__ uint32_t saturate_u32(unsigned long long v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; }
 
 __global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t n_tiles, uint32_t bits, const TileArgs *__restrict__ group)
 {
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t 
     WorkItem *const order = const_cast<WorkItem *>(a.order);
     // (a fused launch's list lengths live in its table entry, zeroed by the host with the table)
     uint32_t *const lengths = group ? const_cast<uint32_t *>(group[blockIdx.y].list_len) : tile_count + n_tiles;
-    uint32_t *const pool_cursor = tile_count + n_tiles + ORDER_POOL;
+    unsigned long long *const pool_cursor = order_pool_cursor(tile_count + n_tiles);
     const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const bool live = i < n_tiles;
@@ -370,50 +379,52 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t 
     // the wave's tiles take one contiguous piece of the pool: running sum over the lanes, the waves' sums over
     // the workgroup, ONE atomic per workgroup (every tile of every frame of a group passes through this one
     // word, and a single address takes ~90 atomics per microsecond)
-    uint32_t incl = n;
+    unsigned long long incl = n;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, d, 64);
         if ((int)lane >= d) incl += up;
     }
-    const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
-    __shared__ uint32_t s_total[ORDER_THREADS / 64], s_base;
+    const unsigned long long wave_total = (unsigned long long)__shfl((long long)incl, 63, 64);
+    __shared__ unsigned long long s_total[ORDER_THREADS / 64], s_base;
     if (lane == 0u) s_total[threadIdx.x >> 6] = wave_total;
     __syncthreads();
-    uint32_t block_total = 0u, before = 0u;
+    unsigned long long block_total = 0u, before = 0u;
 #pragma unroll
     for (int w = 0; w < ORDER_THREADS / 64; w++) {
         if ((uint32_t)w < (threadIdx.x >> 6)) before += s_total[w];
         block_total += s_total[w];
     }
     // (the list atomics and the pool atomic are in flight together)
-    uint32_t base = 0u, pool_base = 0u;
+    uint32_t base = 0u;
+    unsigned long long pool_base = 0u;
     if (lane < (uint32_t)ORDER_BUCKETS && mine) base = atomicAdd(&lengths[lane], mine);
     if (threadIdx.x == 0u && block_total) pool_base = atomicAdd(pool_cursor, block_total);
     if (threadIdx.x == 0u) s_base = pool_base;
     const uint32_t pos = (uint32_t)__shfl((int)base, (int)bk, 64) + rank;
     __syncthreads();
-    const uint32_t wave_base = s_base + before;
-    const uint32_t offset = wave_base + (incl - n);
-    if (lane == 0u && wave_total && (uint64_t)wave_base + wave_total > a.pool_cap) {
+    const unsigned long long wave_base = s_base + before;
+    const unsigned long long offset = wave_base + (incl - n);
+    if (lane == 0u && wave_total && wave_base + wave_total > a.pool_cap) {
         // the pass wants more records than the pool holds: the frame is truncated, the host grows the pools to at
         // least what has been asked for so far and renders again
         atomicOr(a.err, (uint32_t)DE_BIN_OVERFLOW);
         *a.alarm = 1u;
-        atomicMax(a.bin_need, wave_base + wave_total);
+        atomicMax(a.bin_need, saturate_u32(wave_base + wave_total));
         atomicMin(a.overflow_seq, a.pass_seq);
     }
     if (live) {
         WorkItem w;
         w.tile = t;
         // a tile whose range leaves the pool: what fits (k_bin writes no further)
-        w.count = offset >= a.pool_cap ? 0u : min(n, a.pool_cap - offset);
-        w.offset = offset;
+        w.count = offset >= a.pool_cap ? 0u : min(n, a.pool_cap - (uint32_t)offset);
+        w.offset = saturate_u32(offset);
         w.pad = 0u;
         order[(size_t)bk * n_tiles + pos] = w;
         // k_bin counts the tile's counter down from the END of its range: what an atomic returns is the record's
-        // place in the pool; the tile kernel's workgroup for the tile zeroes the counter for the set's next pass
-        if (n) tile_count[t] = offset + n;
+        // place in the pool (a place beyond the pool -- pools hold fewer than 2^31 records -- is not written); the
+        // tile kernel's workgroup for the tile zeroes the counter for the set's next pass
+        if (n) tile_count[t] = saturate_u32(offset + n);
     }
 }
 
@@ -1354,11 +1365,15 @@ __global__ __launch_bounds__(256) void k_push_tiles(const uint8_t *__restrict__ 
                                                     const uint32_t *__restrict__ fb_clean, uint32_t *remote_clean, DevFrame frame,
                                                     const uint32_t *poisoned, unsigned long long *bytes)
 {
-    if (__hip_atomic_load(poisoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+    // one load of the error word per workgroup, then a uniform branch: a time-out raised on another copy stream
+    // while this kernel runs must not split the workgroup around the barrier
+    __shared__ uint32_t s_poisoned;
+    if (threadIdx.x == 0u) s_poisoned = __hip_atomic_load(poisoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t t = blockIdx.x;
     const bool zeros = fb_clean[t] != 0u;
     const bool remote_zeros = remote_clean[t] != 0u;
     __syncthreads();  // (every thread has read the remote flag before thread 0 changes it)
+    if (s_poisoned != 0u) return;
     if (zeros && remote_zeros) return;
     const int32_t W = (int32_t)frame.width, H = (int32_t)frame.height;
     const int32_t x0 = (int32_t)(t % frame.ntx) * TILE_W, y0 = (frame.ty_base + (int32_t)(t / frame.ntx)) * TILE_H;

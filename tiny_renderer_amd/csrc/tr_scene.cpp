@@ -58,9 +58,15 @@ struct HostAlloc {
     size_t bytes;
     void *device;
     uint64_t serial;  // (an address can come back from a later allocation: what a scene remembers is about THIS one)
+    // Who wrote the buffer last, and how often anybody has: a scene's record of the buffer's zero tiles (HostFlags)
+    // holds only while that scene was the last writer and nobody has written since -- another scene reading back
+    // into the same buffer, or tr_scene_host_buffer_written, moves `gen` on and every record of the buffer lapses
+    uint64_t writer;
+    uint64_t gen;
 };
 std::mutex g_host_mutex;
 uint64_t g_host_serial = 0;
+uint64_t g_scene_serial = 0;  // tr_scene::id
 std::map<void *, HostAlloc> g_host_allocs;
 
 struct PassDesc {
@@ -139,6 +145,7 @@ constexpr int GROUP_MAX = 32;   // frames per fused launch, at most
 constexpr int GROUP_SETS = 4;   // groups in flight: group g's setup reuses the bins of group g - GROUP_SETS
 
 struct tr_scene {
+    uint64_t id = 0;  // unique per scene of the process (who wrote a tr_host_alloc buffer last)
     uint32_t width = 0, height = 0;
     int pipeline = 0;
     int device = 0;
@@ -231,6 +238,9 @@ struct tr_scene {
     std::vector<FrameSlot> slots;
     int cur_slot = 0;
     uint32_t frames_per_launch = 0;  // tr_options.frames_per_launch; 0 = by tile count
+    uint32_t max_slots = 0;          // tr_options.max_frame_slots; 0 = automatic
+    bool no_long_runs = false;       // the large groups' resources did not fit the device once: the usual groups from then on
+    bool broken = false;             // a tile kernel could not be launched behind its chain: counters and ranges are stale
     // One group in flight: bins, counters, work lists and argument tables of its frames' passes
     struct GroupSet {
         Piece *bins = nullptr;      // [pass][frame] x pool_cap records
@@ -292,6 +302,7 @@ struct tr_scene {
         void *host;
         uint64_t serial;
         uint32_t *clean;
+        uint64_t gen;  // HostAlloc::gen as this scene's last read-back into the buffer left it
     };
     std::vector<HostFlags> host_flags;
     uint64_t *d_stamps = nullptr;
@@ -331,7 +342,15 @@ namespace {
 template <typename T>
 int dev_alloc(T **p, size_t count)
 {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T));
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();  // (not sticky: the caller may go on with less)
+        *p = nullptr;
+        char buf[96];
+        snprintf(buf, sizeof buf, "out of device memory (%zu bytes)", (count ? count : 1) * sizeof(T));
+        return tr::fail(TR_E_NOMEM, buf);
+    }
+    HIP_TRY(e);
     return TR_OK;
 }
 
@@ -502,10 +521,12 @@ int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
     if (!s->profiling) {
         int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
         if (rc) status = launch_status(rc, "k_tile");
+        if (rc) s->broken = true;  // (its chain has run: the set's counters were not zeroed, the pass's ranges never consumed)
     } else {
         EventPair ep = { take_event(s), take_event(s), t.kernel_id, 1u };
         int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, ep.a, ep.b);
         if (rc) status = launch_status(rc, "k_tile");
+        if (rc) s->broken = true;
         s->events.push_back(ep);
         if (hipEventRecord(s->ev_tile[t.p_seq % RING], s->stream) != hipSuccess && status == TR_OK)
             status = tr::fail(TR_E_HIP, "hipEventRecord");
@@ -1027,13 +1048,14 @@ uint32_t group_size(const tr_scene *s)
 {
     static const int forced = getenv("TR_GROUP") ? atoi(getenv("TR_GROUP")) : 0;  // experiment hook
     if (s->d_winner) return 1u;
-    if (forced >= 1 && forced <= GROUP_MAX) return (uint32_t)forced;
-    if (s->frames_per_launch) return s->frames_per_launch;
+    if (forced >= 1 && forced <= GROUP_MAX) return s->max_slots && (uint32_t)forced > s->max_slots ? s->max_slots : (uint32_t)forced;
+    if (s->frames_per_launch) return s->frames_per_launch;  // (create() has checked it against max_frame_slots)
     uint32_t g = s->n_tiles ? 32768u / s->n_tiles : (uint32_t)GROUP_MAX;
     g = g < 4u ? 4u : g > (uint32_t)GROUP_MAX ? (uint32_t)GROUP_MAX : g;
     // the sets of bins of the groups in flight stay below 48 GiB (a 16384^2 frame: 3 GiB of bins per pass)
     const uint64_t per_frame = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * (uint64_t)kPipelines[s->pipeline].n_passes;
     while (g > 1u && (uint64_t)GROUP_SETS * g * per_frame > (48ull << 30)) g--;
+    if (s->max_slots && g > s->max_slots) g = s->max_slots;
     return g;
 }
 
@@ -1046,12 +1068,13 @@ uint32_t group_size(const tr_scene *s)
 uint32_t long_run_group_size(const tr_scene *s)
 {
     const uint32_t G = group_size(s);
-    if (s->d_winner || s->d_stamps || s->frames_per_launch || getenv("TR_GROUP")) return G;
+    if (s->d_winner || s->d_stamps || s->frames_per_launch || getenv("TR_GROUP") || s->no_long_runs) return G;
     const uint64_t np = (uint64_t)kPipelines[s->pipeline].n_passes;
     const uint64_t slot_bytes = (uint64_t)s->width * s->height * (4ull * np + 3ull);
     const uint64_t set_bytes = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * np;
     uint32_t g = (uint32_t)GROUP_MAX;
     while (g > G && (g * slot_bytes > (8ull << 30) || (uint64_t)GROUP_SETS * g * set_bytes > (16ull << 30))) g /= 2u;
+    if (s->max_slots && g > s->max_slots) g = s->max_slots;
     return g < G ? G : g;
 }
 
@@ -1086,6 +1109,8 @@ size_t group_bins_per_frame(const tr_scene *s) { return (size_t)s->pool_cap * s-
 size_t group_recs_per_frame(const tr_scene *s) { return (size_t)(s->mesh.n_tri ? s->mesh.n_tri : 1u) * s->rec_pieces; }
 size_t group_counts_per_frame(const tr_scene *s) { return (size_t)s->n_tiles_full + 16u; }
 
+void free_group_set(tr_scene::GroupSet &gs);
+
 int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
 {
     const size_t np = (size_t)kPipelines[s->pipeline].n_passes;
@@ -1099,19 +1124,10 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
         gs.in_flight = false;
     }
     if (gs.frames < frames) {
-        dev_free(gs.count);
-        dev_free(gs.order);
-        dev_free(gs.recs);
-        dev_free(gs.lit);
-        dev_free(gs.d_tables);
-        if (gs.h_tables) (void)hipHostFree(gs.h_tables);
-        gs.h_tables = nullptr;
-        dev_free(gs.bins);
-        gs.pool_cap = 0;
-        gs.frames = 0;
+        free_group_set(gs);
         const size_t nc = np * frames * group_counts_per_frame(s);
         if ((st = dev_alloc(&gs.count, nc))) return st;
-        // (from here on k_order zeroes the counters it has read.)  hipMemset returns before the device has
+        // (from here on every tile kernel workgroup zeroes its tile's counter.)  hipMemset returns before the device has
         // executed it and the scene's streams do not wait for the null stream: without the synchronisation the
         // set's first k_setup could count on top of whatever the fresh allocation held (an intermittent "bin
         // overflow" the first time a fourth group was in flight)
@@ -1141,17 +1157,60 @@ int slot_own_fb(tr_scene *s, int k, uint8_t **out);
 // flight -- allocated once, the first time the scene sees frames in bulk (a tr_scene_render_frames call of more than
 // one group, or a group that filled up under the per-frame protocol): a few milliseconds and, at 4096^2, 4 GiB that a
 // later, longer run must not pay for in its own time (a warm-up of five frames, then the timed twenty or two thousand).
+void free_group_set(tr_scene::GroupSet &gs)
+{
+    dev_free(gs.count);
+    dev_free(gs.order);
+    dev_free(gs.recs);
+    dev_free(gs.lit);
+    dev_free(gs.d_tables);
+    if (gs.h_tables) (void)hipHostFree(gs.h_tables);
+    gs.h_tables = nullptr;
+    dev_free(gs.bins);
+    gs.pool_cap = 0;
+    gs.frames = 0;
+}
+
 int prepare_long_runs(tr_scene *s, bool own_colour)
 {
     const uint32_t g = long_run_group_size(s);
     if (g <= group_size(s) || s->d_winner) return TR_OK;
+    const size_t slots_before = s->slots.size();
     int st = ensure_slots(s, g);
     for (uint32_t k = 0; k < g && st == TR_OK && own_colour; k++) {
         uint8_t *unused = nullptr;
         st = slot_own_fb(s, (int)k, &unused);
     }
     for (int k = 0; k < GROUP_SETS && st == TR_OK; k++) st = ensure_group_set(s, s->grp[k], g);
-    return st;
+    if (st != TR_E_NOMEM) return st;
+    // The device has no room for a long run's resources (a smaller GPU, several scenes or ranks on one): give back
+    // what was taken just now -- nothing has used it -- and go on with the usual groups, for good.
+    const std::string why = tr::g_last_error;
+    (void)hipStreamSynchronize(s->stream);  // (the new colour buffers' zero fill)
+    const uint32_t G = group_size(s);
+    while (s->slots.size() > slots_before && s->slots.size() > (size_t)G) {
+        tr_scene::FrameSlot &fs = s->slots.back();
+        if (fs.fb)
+            for (size_t k = 0; k < s->fb_flags.size(); k++)
+                if (s->fb_flags[k].fb == fs.fb && s->fb_flags[k].clean != s->d_fbclean) {
+                    dev_free(s->fb_flags[k].clean);
+                    s->fb_flags.erase(s->fb_flags.begin() + (long)k);
+                    break;
+                }
+        dev_free(fs.z);
+        dev_free(fs.zclean);
+        if (fs.shadow != s->slots[0].shadow) {
+            dev_free(fs.shadow);
+            dev_free(fs.sclean);
+        }
+        dev_free(fs.fb);
+        s->slots.pop_back();
+    }
+    for (tr_scene::GroupSet &gs : s->grp)
+        if (!gs.in_flight && gs.frames > G) free_group_set(gs);
+    s->no_long_runs = true;
+    tr::g_last_error = "large frame groups disabled for this scene: " + why;
+    return TR_OK;
 }
 
 int submit_groups(tr_scene *s, bool all);
@@ -1327,7 +1386,10 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
         const bool last = pi + 1u == np;
         int rc = launch_tile(tile_fs(s, pass.fs), ta0, tile_waves, shared, s->mesh.n_tri, d_tile + (size_t)pi * G, g, s->stream, ep.a,
                              (!s->profiling && last) ? gs.ev_tile : ep.b);
-        if (rc) return launch_status(rc, "k_tile");
+        if (rc) {
+            s->broken = true;  // (the group's chains have run: counters not zeroed, ranges never consumed)
+            return launch_status(rc, "k_tile");
+        }
         if (s->profiling) s->events.push_back(ep);
     }
     if (s->profiling) HIP_TRY(hipEventRecord(gs.ev_tile, s->stream));
@@ -1474,14 +1536,20 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     // (its tile kernel starts as early as it can), every later one up to four times the one before -- its setup chain
     // still hides behind the tile kernel in front of it.
     const uint32_t Gmax = n >= 16u * G ? long_run_group_size(s) : G;
-    static const uint32_t growth = getenv("TR_GROUP_GROWTH") ? (uint32_t)atoi(getenv("TR_GROUP_GROWTH")) : 4u;  // experiment hook
+    static const uint32_t growth = [] {  // experiment hook (at least 2: a group must be able to grow)
+        const int v = getenv("TR_GROUP_GROWTH") ? atoi(getenv("TR_GROUP_GROWTH")) : 4;
+        return (uint32_t)(v < 2 ? 2 : v);
+    }();
     std::vector<uint32_t> sizes;
     uint32_t largest = 0;
     // A SHORT call (fewer than sixteen groups) is mostly start-up and gaps: its first group is the usual one -- the host
     // has four frames to prepare, not ten, before the first kernel can start, and the chain in front of the first tile
     // kernel is the short one -- and every later group up to twice the one before (its chain hides behind the tile
     // kernel in front), up to three times the usual size: twenty frames at 4096^2 = 4 + 8 + 8, two gaps instead of four.
-    static const uint32_t short_factor = getenv("TR_SHORT_GROUPS") ? (uint32_t)atoi(getenv("TR_SHORT_GROUPS")) : 3u;  // experiment hook
+    static const uint32_t short_factor = [] {  // experiment hook (1 = the usual group throughout)
+        const int v = getenv("TR_SHORT_GROUPS") ? atoi(getenv("TR_SHORT_GROUPS")) : 3;
+        return (uint32_t)(v < 1 ? 1 : v);
+    }();
     const bool automatic = !s->d_winner && !s->d_stamps && !s->frames_per_launch && !getenv("TR_GROUP");
     if (automatic && n > G && Gmax == G && short_factor > 1u) {
         uint32_t cap = short_factor * G < (uint32_t)GROUP_MAX ? short_factor * G : (uint32_t)GROUP_MAX;
@@ -1706,6 +1774,10 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
     s->tile_mode = o.tile_mode;
     if (o.frames_per_launch > (uint32_t)GROUP_MAX) return tr::fail(TR_E_INVALID, "frames_per_launch must be 0 (automatic) or 1..32");
     s->frames_per_launch = o.frames_per_launch;
+    if (o.max_frame_slots > (uint32_t)GROUP_MAX) return tr::fail(TR_E_INVALID, "max_frame_slots must be 0 (automatic) or 1..32");
+    if (o.max_frame_slots && o.frames_per_launch > o.max_frame_slots)
+        return tr::fail(TR_E_INVALID, "frames_per_launch exceeds max_frame_slots (every frame of a launch needs a slot)");
+    s->max_slots = o.max_frame_slots;
     s->auto_group = (o.flags & TR_OPT_NO_AUTO_GROUP) == 0;
 
     if (o.stream) {
@@ -2044,6 +2116,10 @@ int tr_scene_create(uint32_t width, uint32_t height, const tr_mesh *mesh, const 
     if (!out) return tr::fail(TR_E_INVALID, "null out pointer");
     *out = nullptr;
     tr_scene *s = new tr_scene();
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        s->id = ++g_scene_serial;
+    }
     int st = create(width, height, mesh, tex, pipeline_name, opts, s);
     if (st != TR_OK) {
         std::string keep = tr::g_last_error;
@@ -2084,6 +2160,7 @@ int tr_scene_set_camera(tr_scene *s, const float look_from[3], const float look_
 int tr_scene_render(tr_scene *s)
 {
     if (!s) return tr::fail(TR_E_INVALID, "null scene");
+    if (s->broken) return tr::fail(TR_E_HIP, "the scene is unusable: a tile kernel could not be launched behind its chain");
     HIP_TRY(hipSetDevice(s->device));
     memcpy(s->last.light, s->light, 12);
     memcpy(s->last.from, s->from, 12);
@@ -2129,6 +2206,7 @@ int tr_scene_render(tr_scene *s)
 int tr_scene_render_frames(tr_scene *s, uint32_t n_frames, const tr_frame_params *frames, void *const *frame_buffers_device)
 {
     if (!s || (n_frames && !frames)) return tr::fail(TR_E_INVALID, "null argument");
+    if (s->broken) return tr::fail(TR_E_HIP, "the scene is unusable: a tile kernel could not be launched behind its chain");
     if (n_frames == 0) return TR_OK;
     if (frame_buffers_device)
         for (uint32_t i = 0; i < n_frames; i++)
@@ -2239,24 +2317,41 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
     // same stream as the tile kernels: after the frame, before the next one overwrites it.  Into memory from
     // tr_host_alloc only the tiles that are not zeros on both sides travel (k_read_back); any other buffer gets
     // the whole frame from the copy engine.
+    // The sparse form needs a scene that renders the WHOLE frame: k_read_back writes the tiles of the scene's band only,
+    // and "the buffer ends up holding the complete frame" must hold for a band scene too (whose other rows, in a
+    // caller's all-gather buffer, come from other ranks): such a scene takes the copy engine.
+    const bool whole_frame = s->frame.band_y0 == 0 && s->frame.band_y1 == (int32_t)s->height;
     void *mapped = nullptr;
-    uint64_t serial = 0;
+    uint64_t serial = 0, gen = 0;
+    bool mine = false;  // this scene was the buffer's last writer
     {
         std::lock_guard<std::mutex> lock(g_host_mutex);
         auto it = g_host_allocs.find(rgb);
-        if (it != g_host_allocs.end() && it->second.bytes >= bytes) {
-            mapped = it->second.device;
-            serial = it->second.serial;
+        if (it != g_host_allocs.end()) {
+            if (it->second.bytes >= bytes && whole_frame && s->width % 16u == 0u && s->d_fbclean) {
+                mapped = it->second.device;
+                serial = it->second.serial;
+                mine = it->second.writer == s->id;
+                gen = it->second.gen;
+            }
+            // (whichever way the frame travels: from now on this scene is the last writer, and every other scene's
+            // record of the buffer has lapsed)
+            it->second.writer = s->id;
+            it->second.gen += 1u;
+            if (mapped) gen = it->second.gen - 1u;
         }
     }
-    if (mapped && s->width % 16u == 0u && s->d_fbclean) {
+    if (mapped) {
         uint32_t *host_clean = nullptr;
         for (tr_scene::HostFlags &f : s->host_flags)
             if (f.host == rgb) {
-                if (f.serial != serial) {  // the address of a buffer that has been freed: another buffer now
+                // the address of a buffer that has been freed (another buffer now), or somebody else -- another scene's
+                // read-back, the caller (tr_scene_host_buffer_written) -- has written the buffer since: content unknown
+                if (f.serial != serial || !mine || f.gen != gen) {
                     HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
                     f.serial = serial;
                 }
+                f.gen = gen + 1u;
                 host_clean = f.clean;
             }
         if (!host_clean) {
@@ -2267,7 +2362,7 @@ int tr_scene_get_frame_buffer_async(tr_scene *s, uint8_t *rgb)
             }
             if ((st = dev_alloc(&host_clean, (size_t)s->n_tiles))) return st;
             HIP_TRY(hipMemsetAsync(host_clean, 0, (size_t)s->n_tiles * 4, s->stream));  // content of the buffer unknown
-            s->host_flags.push_back({ rgb, serial, host_clean });
+            s->host_flags.push_back({ rgb, serial, host_clean, gen + 1u });
         }
         int rc = launch_read_back(s->d_fb, (uint8_t *)mapped, s->d_fbclean, host_clean, s->frame, s->stream);
         if (rc) return launch_status(rc, "k_read_back");
@@ -2316,7 +2411,7 @@ void *tr_host_alloc(size_t bytes)
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) d = nullptr;
     if (d) {
         std::lock_guard<std::mutex> lock(g_host_mutex);
-        g_host_allocs[p] = { bytes, d, ++g_host_serial };
+        g_host_allocs[p] = { bytes, d, ++g_host_serial, 0u, 0u };
     }
     return p;
 }
@@ -2334,9 +2429,13 @@ void tr_host_free(void *p)
 int tr_scene_host_buffer_written(tr_scene *s, void *p)
 {
     if (!s || !p) return tr::fail(TR_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
-    for (const tr_scene::HostFlags &f : s->host_flags)
-        if (f.host == p) HIP_TRY(hipMemsetAsync(f.clean, 0, (size_t)s->n_tiles * 4, s->stream));
+    // nobody's record of the buffer holds any more (this scene's, and any other scene's that reads back into it)
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    auto it = g_host_allocs.find(p);
+    if (it != g_host_allocs.end()) {
+        it->second.writer = 0u;
+        it->second.gen += 1u;
+    }
     return TR_OK;
 }
 

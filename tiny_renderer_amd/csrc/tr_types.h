@@ -199,8 +199,9 @@ struct TileArgs {
     // The pass's work lists (k_order, from this pass's counters): eight regions of n_tiles entries, region b =
     // the tiles of weight class b as (tile, polygons in its bin), the last region the empty tiles.
     const WorkItem *order;
-    // This pass's counter set: n_tiles counters (k_order has zeroed them again), then 16 words, the first eight
-    // of which hold the lists' lengths of a per-frame launch.  A fused launch's lengths are in its table entry
+    // This pass's counter set: n_tiles counters (k_order leaves the end of the tile's pool range in each, k_bin counts
+    // it down to the start, the tile's k_tile workgroup zeroes it for the set's next pass), then 16 words, the first
+    // eight of which hold the lists' lengths of a per-frame launch, the next the 64-bit pool cursor.  A fused launch's lengths are in its table entry
     // (list_len, zeroed by the host, filled by k_order): the tile kernel finds them with its other arguments
     // instead of behind one more dependent load.
     uint32_t *tile_count;

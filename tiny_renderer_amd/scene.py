@@ -39,7 +39,7 @@ class Scene:
     def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
                  winner_tap=False, tile_stamps=False, band_rows=None, stream=None, frame_buffer_device=None,
                  bin_capacity=0, tile_waves=0, tile_mode=0, frames_per_launch=0, auto_group=True,
-                 trust_frame_buffers=False):
+                 trust_frame_buffers=False, max_frame_slots=0):
         L = load_library()
         self.width, self.height = int(width), int(height)
         keep = []
@@ -65,6 +65,7 @@ class Scene:
         o.tile_waves = int(tile_waves)
         o.tile_mode = int(tile_mode)
         o.frames_per_launch = int(frames_per_launch)
+        o.max_frame_slots = int(max_frame_slots)
         h = C.c_void_p()
         self._h = None
         self._pinned = []
