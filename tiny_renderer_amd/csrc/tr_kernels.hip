@@ -63,21 +63,17 @@ __device__ __forceinline__ int32_t tile_index(const DevFrame &f, int32_t tx, int
 constexpr uint32_t CHAIN_WAVES = 4;
 constexpr uint32_t CHAIN_THREADS = 64 * CHAIN_WAVES;
 
-template <int VS>
-__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
+// Polygon t's record (P pieces) for the pass `a` describes: vertex closure, truncating projection, clamped box.
+// A polygon that draws nothing (culled, off screen, degenerate, t beyond the mesh) gets the canonical empty box
+// (bx0 = 1 > bx1 = 0) and nothing else.  Returns the device error bits the vertex stage raised.
+template <int VS, int P>
+__device__ __forceinline__ uint32_t setup_record(const SetupArgs &a, uint32_t t, uint4 (&o)[P])
 {
-    constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    // Lane = polygon: vertex closure, truncating projection, clamped box; the polygon's record goes to the pass's
-    // record array ONCE (k_bin copies it to the tiles), its tiles' counters are bumped with atomics that return
-    // nothing, so nothing waits for them.
-    __builtin_amdgcn_s_setprio(3);  // (see k_order)
-    const uint32_t lane = threadIdx.x;
-    const uint32_t t = block * blockDim.x + lane;
-    // the 16 words behind this pass's counters (k_order's list lengths and pool cursor): their last readers --
-    // the tile kernel of the pass that had the set before -- are done (the host orders that)
-    if (block == 0u && lane < 16u) a.tile_count[a.frame.ntx * a.frame.nty + lane] = 0u;
-    if (t >= a.mesh.n_tri) return;
     uint32_t err = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) o[i] = make_uint4(0u, 0u, 0u, 0u);
+    o[0] = make_uint4(1u, 0u, 0u, 0u);
+    if (t >= a.mesh.n_tri) return 0u;
     RasterRec r;
     float v[VARY_STRIDE];
 #pragma unroll
@@ -87,13 +83,11 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
         finish_raster_rec(r, a.frame);
     else
         mark_rejected(r);
-    uint4 *o = reinterpret_cast<uint4 *>(a.recs) + (size_t)t * P;
     // piece 0: the clamped box (coordinates below 2^15; bx0 = 1 > bx1 = 0: draws nothing) and, in a tile's copy,
     // the pair's coverage masks (pair_masks, tr_shaders.h: filled in by k_bin)
     // (a polygon that draws nothing may have any coordinates: it gets the canonical empty box)
-    o[0] = r.bx0 <= r.bx1 ? make_uint4((uint32_t)r.bx0 | ((uint32_t)r.bx1 << 16), (uint32_t)r.by0 | ((uint32_t)r.by1 << 16), 0u, 0u)
-                          : make_uint4(1u, 0u, 0u, 0u);
     if (r.bx0 <= r.bx1) {
+        o[0] = make_uint4((uint32_t)r.bx0 | ((uint32_t)r.bx1 << 16), (uint32_t)r.by0 | ((uint32_t)r.by1 << 16), 0u, 0u);
         // vertex 0 and the two edge vectors from it, the latter already as the f32 values every
         // pixel's to_barycentric_coord starts from (scene.rs:178-181: integer difference, then
         // the conversion) -- the tile kernel's shading phase used to redo these 8 subtractions
@@ -110,11 +104,105 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
         // per polygon; k_tile derives every per-pixel quotient from it (tr_math.h div_by)
         o[P - 1] = make_uint4(__float_as_uint(v[4 * (P - 1) - 14]), __float_as_uint(v[4 * (P - 1) - 13]),
                               __float_as_uint(v[4 * (P - 1) - 12]), __float_as_uint(record_recip(r)));
-        const int32_t tx0 = r.bx0 / TILE_W, tx1 = r.bx1 / TILE_W, ty0 = r.by0 / TILE_H, ty1 = r.by1 / TILE_H;
-        for (int32_t ty = ty0; ty <= ty1; ty++)
-            for (int32_t tx = tx0; tx <= tx1; tx++)
-                __hip_atomic_fetch_add(&a.tile_count[tile_index(a.frame, tx, ty)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    return err;
+}
+
+// The (polygon, tile) pairs of a wave whose lane l holds the box of one polygon (or the empty box): numbered by a
+// prefix sum over the lanes, so that they can be dealt to all 64 lanes -- a polygon that spans 40 tiles is 40 lanes'
+// work for one step, not one lane's loop of 40 while the others idle.
+struct PairDeal {
+    int32_t corner, ntx, excl, total;  // this lane's polygon: first tile column | first tile row << 16, tile columns, pairs before it
+    __device__ __forceinline__ PairDeal(const uint4 &piece0)
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        const int32_t bx0 = (int32_t)(piece0.x & 0xFFFFu), bx1 = (int32_t)(piece0.x >> 16);
+        const int32_t by0 = (int32_t)(piece0.y & 0xFFFFu), by1 = (int32_t)(piece0.y >> 16);
+        int32_t cnt = 0;
+        corner = 0;
+        ntx = 1;
+        if (bx0 <= bx1) {
+            corner = bx0 / TILE_W | (by0 / TILE_H) << 16;
+            ntx = bx1 / TILE_W - bx0 / TILE_W + 1;
+            cnt = ntx * (by1 / TILE_H - by0 / TILE_H + 1);
+        }
+        int32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t up = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += up;
+        }
+        total = __shfl(incl, 63, 64);
+        excl = incl - cnt;
+    }
+    // pair p (every lane of the wave calls this together; p may lie beyond `total`): the lane that holds its polygon
+    // and the tile; false beyond the last pair
+    __device__ __forceinline__ bool locate(int32_t p, int32_t &owner, int32_t &ptx, int32_t &pty) const
+    {
+        // owner = last lane whose exclusive offset is <= p (lanes without pairs share their successor's offset, so
+        // "last" skips them)
+        int32_t lo = 0, hi = 63;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (__shfl(excl, mid, 64) <= p)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const int32_t q = p - __shfl(excl, lo, 64), w = __shfl(ntx, lo, 64), c = __shfl(corner, lo, 64);
+        owner = lo;
+        ptx = (c & 0xFFFF) + q % w;
+        pty = (c >> 16) + q / w;
+        return p < total;
+    }
+};
+
+// Bumps the counter of every tile the wave's polygons' boxes meet (atomics that return nothing: nothing waits for them).
+__device__ __forceinline__ void count_tiles(const SetupArgs &a, const uint4 &piece0)
+{
+    const PairDeal deal(piece0);
+    const int32_t lane = (int32_t)(threadIdx.x & 63u);
+    for (int32_t p0 = 0; p0 < deal.total; p0 += 64) {
+        int32_t owner, ptx, pty;
+        if (deal.locate(p0 + lane, owner, ptx, pty))
+            __hip_atomic_fetch_add(&a.tile_count[tile_index(a.frame, ptx, pty)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Which polygon a lane of the chain's kernels takes.  The first `polys` lanes of every wave take one each, INTERLEAVED
+// over the launch's waves (lane l of wave w: polygon l * waves + w): neighbours in a mesh are neighbours on the screen
+// and of similar size -- in mesh order one wave got the eight largest polygons of the reference's model and was the
+// critical path of the whole chain (k_bin's waves: median 3.4 us, slowest 13).
+__device__ __forceinline__ uint32_t chain_polygon(uint32_t block, uint32_t polys)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = block * (blockDim.x >> 6) + (threadIdx.x >> 6), waves = gridDim.x * (blockDim.x >> 6);
+    return lane < polys ? lane * waves + wave : 0xFFFFFFFFu;
+}
+
+template <int VS>
+__device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block, uint32_t polys)
+{
+    constexpr int P = (VS == VS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
+    // Lane = polygon: vertex closure, truncating projection, clamped box; the polygon's record goes to the pass's
+    // record array ONCE (k_bin copies it to the tiles), its tiles' counters are bumped with atomics that return
+    // nothing, so nothing waits for them.
+    __builtin_amdgcn_s_setprio(3);  // (see k_order)
+    // the 16 words behind this pass's counters (k_order's list lengths and pool cursor): their last readers --
+    // the tile kernel of the pass that had the set before -- are done (the host orders that)
+    if (block == 0u && threadIdx.x < 16u) a.tile_count[a.frame.ntx * a.frame.nty + threadIdx.x] = 0u;
+    const uint32_t t = chain_polygon(block, polys);
+    uint4 rec[P];
+    const uint32_t err = setup_record<VS, P>(a, t, rec);
+    if (t < a.mesh.n_tri) {
+        uint4 *o = reinterpret_cast<uint4 *>(a.recs) + (size_t)t * P;
+        o[0] = rec[0];
+        if ((rec[0].x & 0xFFFFu) <= (rec[0].x >> 16)) {
+#pragma unroll
+            for (int i = 1; i < P; i++) o[i] = rec[i];
+        }
+    }
+    count_tiles(a, rec[0]);
     if (err) {
         atomicOr(a.err, err);
         *a.alarm = 1u;
@@ -122,9 +210,9 @@ __device__ __forceinline__ void setup_body(const SetupArgs &a, uint32_t block)
 }
 
 template <int VS>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_setup(SetupArgs a)
+__global__ __launch_bounds__(CHAIN_THREADS) void k_setup(SetupArgs a, uint32_t polys)
 {
-    setup_body<VS>(a, blockIdx.x);
+    setup_body<VS>(a, blockIdx.x, polys);
 }
 
 // k_bin: copies every polygon's record into the range of each tile its box meets, with the pair's coverage masks.
@@ -142,40 +230,16 @@ __device__ __forceinline__ uint4 shuffle_piece(const uint4 &v, int32_t from)
                       (uint32_t)__shfl((int)v.w, from, 64));
 }
 
+// The wave's polygons are in its lanes' registers (`mine`: lane l holds one record, or the empty box): their
+// (polygon, tile) pairs are numbered by a prefix sum and dealt to all 64 lanes, which fetch the record from the
+// owner lane with shuffles (no LDS: nothing to fit beside the tile kernel's workgroups, no barrier).
 template <int P>
-__device__ __forceinline__ void bin_body(const SetupArgs &a, uint32_t block, uint32_t polys)
+__device__ __forceinline__ void bin_deal(const SetupArgs &a, const uint4 (&mine)[P])
 {
-    __builtin_amdgcn_s_setprio(3);  // (see k_order)
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t = (block * (blockDim.x >> 6) + (threadIdx.x >> 6)) * polys + lane;
-    int32_t corner = 0, ntx = 1, cnt = 0;  // corner: first tile column | first tile row << 16
-    // the lane's polygon, in registers: the lanes that copy it to a tile fetch it from here with shuffles (no LDS:
-    // nothing to fit beside the tile kernel's workgroups, no barrier)
-    uint4 mine[P];
-#pragma unroll
-    for (int i = 0; i < P; i++) mine[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < polys && t < a.mesh.n_tri) {
-        const uint4 *const rec = reinterpret_cast<const uint4 *>(a.recs) + (size_t)t * P;
-#pragma unroll
-        for (int i = 0; i < P; i++) mine[i] = rec[i];  // (a polygon that draws nothing has only its box written: the rest is not used)
-        const int32_t bx0 = (int32_t)(mine[0].x & 0xFFFFu), bx1 = (int32_t)(mine[0].x >> 16);
-        const int32_t by0 = (int32_t)(mine[0].y & 0xFFFFu), by1 = (int32_t)(mine[0].y >> 16);
-        if (bx0 <= bx1) {
-            corner = bx0 / TILE_W | (by0 / TILE_H) << 16;
-            ntx = bx1 / TILE_W - bx0 / TILE_W + 1;
-            cnt = ntx * (by1 / TILE_H - by0 / TILE_H + 1);
-        }
-    }
-    int32_t incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int32_t up = __shfl_up(incl, d, 64);
-        if ((int)lane >= d) incl += up;
-    }
-    const int32_t total = __shfl(incl, 63, 64), excl = incl - cnt;
-
+    const int32_t lane = (int32_t)(threadIdx.x & 63u);
+    const PairDeal deal(mine[0]);
     constexpr int PAIRS = 2;  // pairs per lane per trip: their atomics are in flight together
-    for (int32_t p0 = 0; p0 < total; p0 += 64 * PAIRS) {
+    for (int32_t p0 = 0; p0 < deal.total; p0 += 64 * PAIRS) {
         int32_t own[PAIRS], origin[PAIRS];
         uint32_t at[PAIRS];
         bool have[PAIRS];
@@ -183,31 +247,17 @@ __device__ __forceinline__ void bin_body(const SetupArgs &a, uint32_t block, uin
         for (int k = 0; k < PAIRS; k++) {
             have[k] = false;
             own[k] = 0;
-            if (p0 + 64 * k >= total) continue;  // (uniform)
-            const int32_t p = p0 + 64 * k + (int32_t)lane;
-            // owner = last lane whose exclusive offset is <= p (lanes without pairs share
-            // their successor's offset, so "last" skips them)
-            int32_t lo = 0, hi = 63;
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const int32_t mid = (lo + hi + 1) >> 1;
-                if (__shfl(excl, mid, 64) <= p)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            const int32_t q = p - __shfl(excl, lo, 64), w = __shfl(ntx, lo, 64), c = __shfl(corner, lo, 64);
-            own[k] = lo;
-            have[k] = p < total;
+            if (p0 + 64 * k >= deal.total) continue;  // (uniform)
+            int32_t ptx, pty;
+            have[k] = deal.locate(p0 + 64 * k + lane, own[k], ptx, pty);
             if (have[k]) {
-                const int32_t ptx = (c & 0xFFFF) + q % w, pty = (c >> 16) + q / w;
                 origin[k] = ptx | pty << 16;
                 at[k] = atomicSub(&a.tile_count[tile_index(a.frame, ptx, pty)], 1u) - 1u;
             }
         }
 #pragma unroll
         for (int k = 0; k < PAIRS; k++) {
-            if (p0 + 64 * k >= total) continue;  // (uniform: every lane takes part in the shuffles)
+            if (p0 + 64 * k >= deal.total) continue;  // (uniform: every lane takes part in the shuffles)
             uint4 piece[P];
 #pragma unroll
             for (int i = 0; i < P; i++) piece[i] = shuffle_piece(mine[i], own[k]);
@@ -227,6 +277,24 @@ __device__ __forceinline__ void bin_body(const SetupArgs &a, uint32_t block, uin
 }
 
 template <int P>
+__device__ __forceinline__ void bin_body(const SetupArgs &a, uint32_t block, uint32_t polys)
+{
+    __builtin_amdgcn_s_setprio(3);  // (see k_order)
+    const uint32_t t = chain_polygon(block, polys);
+    // the lane's polygon, in registers
+    uint4 mine[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) mine[i] = make_uint4(0u, 0u, 0u, 0u);
+    mine[0] = make_uint4(1u, 0u, 0u, 0u);
+    if (t < a.mesh.n_tri) {
+        const uint4 *const rec = reinterpret_cast<const uint4 *>(a.recs) + (size_t)t * P;
+#pragma unroll
+        for (int i = 0; i < P; i++) mine[i] = rec[i];  // (a polygon that draws nothing has only its box written: the rest is not used)
+    }
+    bin_deal<P>(a, mine);
+}
+
+template <int P>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_bin(SetupArgs a, uint32_t polys)
 {
     bin_body<P>(a, blockIdx.x, polys);
@@ -241,9 +309,9 @@ using constant_ptr = const __attribute__((address_space(4))) T *;
 // The same for a group of frames in one launch (tr_scene_render_frames): blockIdx.y = frame, whose
 // arguments are entry y of a table in device memory.
 template <int VS>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_setup_group(const SetupArgs *__restrict__ table)
+__global__ __launch_bounds__(CHAIN_THREADS) void k_setup_group(const SetupArgs *__restrict__ table, uint32_t polys)
 {
-    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x);
+    setup_body<VS>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x, polys);
 }
 
 template <int P>
@@ -339,8 +407,6 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t n)
     return lg >= (uint32_t)(ORDER_BUCKETS - 2) ? 0u : (uint32_t)(ORDER_BUCKETS - 2) - lg;
 }
 
-// `group` != null: blockIdx.y = frame of a group, whose counters, work lists and pool are in entry y of the tile
-// kernel's argument table; else `one` describes the pass.
 // The pool cursor: a 64-bit word among the eight words behind the list lengths (at the first 8-byte boundary) -- the
 // pairs a pass WANTS may exceed 2^32 (a million polygons that each cross a large frame) even though no pool can
 // hold them: ranges are formed in 64 bits and saturate, so that "how many records the pass wanted" stays meaningful
@@ -351,23 +417,20 @@ __device__ __forceinline__ unsigned long long *order_pool_cursor(uint32_t *words
 }
 __device__ __forceinline__ uint32_t saturate_u32(unsigned long long v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; }
 
-__global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t n_tiles, uint32_t bits, const TileArgs *__restrict__ group)
+// One workgroup's share of the sweep: tiles block * ORDER_THREADS .. of the pass `a` describes; `lengths`: the eight
+// list lengths (a fused launch keeps them in its table entry, a per-frame launch behind the pass's counters).
+__device__ __forceinline__ void order_body(const TileArgs &a, uint32_t *lengths, uint32_t n_tiles, uint32_t bits, uint32_t block)
 {
-    // The chain in front of a tile kernel is a few hundred waves that share their SIMDs with six tile-kernel waves
-    // each -- at equal priority every instruction of theirs waits its turn behind six others, and the NEXT pass's
-    // tile kernel waits for them.  They are raised: the tile kernel hardly notices a few hundred short waves.
-    __builtin_amdgcn_s_setprio(3);
-    const TileArgs &a = group ? group[blockIdx.y] : one;
     uint32_t *const tile_count = a.tile_count;
     WorkItem *const order = const_cast<WorkItem *>(a.order);
-    // (a fused launch's list lengths live in its table entry, zeroed by the host with the table)
-    uint32_t *const lengths = group ? const_cast<uint32_t *>(group[blockIdx.y].list_len) : tile_count + n_tiles;
     unsigned long long *const pool_cursor = order_pool_cursor(tile_count + n_tiles);
-    const uint32_t i = blockIdx.x * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t i = block * ORDER_THREADS + threadIdx.x, lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const bool live = i < n_tiles;
     const uint32_t t = live ? scatter_tile(i, n_tiles, bits) : 0u;
-    const uint32_t n = live ? tile_count[t] : 0u;
+    // (agent-scope load and store of the counter: inside k_chain they are what other workgroups' atomics made and will
+    // count down, with no kernel boundary in between)
+    const uint32_t n = live ? __hip_atomic_load(&tile_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const uint32_t bk = order_bucket(n);
     uint32_t mine = 0u, rank = 0u;
 #pragma unroll
@@ -424,8 +487,22 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t 
         // k_bin counts the tile's counter down from the END of its range: what an atomic returns is the record's
         // place in the pool (a place beyond the pool -- pools hold fewer than 2^31 records -- is not written); the
         // tile kernel's workgroup for the tile zeroes the counter for the set's next pass
-        if (n) tile_count[t] = saturate_u32(offset + n);
+        if (n) __hip_atomic_store(&tile_count[t], saturate_u32(offset + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// `group` != null: blockIdx.y = frame of a group, whose counters, work lists and pool are in entry y of the tile
+// kernel's argument table; else `one` describes the pass.
+__global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t n_tiles, uint32_t bits, const TileArgs *__restrict__ group)
+{
+    // The chain in front of a tile kernel is a few hundred waves that share their SIMDs with six tile-kernel waves
+    // each -- at equal priority every instruction of theirs waits its turn behind six others, and the NEXT pass's
+    // tile kernel waits for them.  They are raised: the tile kernel hardly notices a few hundred short waves.
+    __builtin_amdgcn_s_setprio(3);
+    const TileArgs &a = group ? group[blockIdx.y] : one;
+    // (a fused launch's list lengths live in its table entry, zeroed by the host with the table)
+    uint32_t *const lengths = group ? const_cast<uint32_t *>(group[blockIdx.y].list_len) : a.tile_count + n_tiles;
+    order_body(a, lengths, n_tiles, bits, blockIdx.x);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -1557,6 +1634,16 @@ int launch_selftest_unary(int which, uint32_t first, uint64_t count, unsigned lo
     } while (0)
 
 int rec_pieces_for_vs(int vs) { return vs == VS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
+
+// Polygons per wave of the chain's kernels: all 64 lanes beside a running tile kernel (throughput: the fewer waves, the
+// less it is disturbed); when the caller's tile kernel WAITS for the chain (`hurry`, see launch_setup) and the mesh is
+// small, 8 -- the wave with the most (polygon, tile) pairs is the critical path
+static uint32_t chain_polys(uint32_t n_tri, uint32_t frames, bool hurry)
+{
+    uint32_t polys = BIN_POLYS;
+    if (hurry && (uint64_t)((n_tri + polys - 1u) / polys) * frames < 2048u) polys = 8u;
+    return polys;
+}
 int rec_pieces_for_fs(int fs) { return fs == FS_DARBOUX ? REC_PIECES_LARGE : REC_PIECES_SMALL; }
 
 int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bool hurry, hipStream_t st,
@@ -1570,14 +1657,16 @@ int launch_setup(int vs, const SetupArgs &a, const SetupArgs *group, uint32_t n_
     // launch always: its chain is as long as the tile kernel it has to hide behind -- the throughput shapes made the
     // unfused per-frame loop 65 us per frame at 4096^2 where these give 38)
     hurry = hurry || !group;
-    const uint32_t threads = hurry ? 64u : CHAIN_THREADS;
-    const dim3 grid(a.mesh.n_tri ? (a.mesh.n_tri + threads - 1u) / threads : 1u, group ? n_frames : 1u), block(threads);
+    // polygons per wave: as k_bin (launch_bin), so that a wave of k_bin finds the boxes a wave of k_setup counted
+    const uint32_t polys = chain_polys(a.mesh.n_tri, group ? n_frames : 1u, hurry);
+    const uint32_t per_group = hurry ? 1u : CHAIN_WAVES, waves = (a.mesh.n_tri + polys - 1u) / polys;
+    const dim3 grid(a.mesh.n_tri ? (waves + per_group - 1u) / per_group : 1u, group ? n_frames : 1u), block(64u * per_group);
 #define TR_SETUP_CASE(V)                                                                   \
     case V:                                                                                \
         if (group)                                                                         \
-            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group); \
+            hipExtLaunchKernelGGL(k_setup_group<V>, grid, block, 0, st, start, done, 0, group, polys); \
         else                                                                               \
-            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a);      \
+            hipExtLaunchKernelGGL(k_setup<V>, grid, block, 0, st, start, done, 0, a, polys);      \
         break;
     switch (vs) {
     TR_SETUP_CASE(VS_DEFAULT)
@@ -1601,9 +1690,8 @@ int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bo
     // disturbed); when the caller's tile kernel WAITS for this chain (`hurry`, see launch_setup) and the mesh is
     // small, 8 -- the wave with the most (polygon, tile) pairs is the critical path (628 waves for 5 022 polygons:
     // 13 us instead of 39)
-    uint32_t polys = BIN_POLYS;
     hurry = hurry || !group;  // (see launch_setup)
-    if (hurry && (uint64_t)((a.mesh.n_tri + polys - 1u) / polys) * (group ? n_frames : 1u) < 2048u) polys = 8u;
+    const uint32_t polys = chain_polys(a.mesh.n_tri, group ? n_frames : 1u, hurry);
     const uint32_t lds = 0u, waves = (a.mesh.n_tri + polys - 1u) / polys;
     const uint32_t per_group = hurry ? 1u : CHAIN_WAVES;
     const dim3 grid((waves + per_group - 1u) / per_group, group ? n_frames : 1u), block(64u * per_group);

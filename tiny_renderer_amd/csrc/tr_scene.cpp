@@ -194,6 +194,11 @@ struct tr_scene {
     // kernel of pass p on the main stream.  They need only frame constants, so they overlap the tile
     // kernels of earlier passes: consecutive frames are in flight together, like any renderer's.
     hipStream_t setup_stream = nullptr;
+    // A second one for the per-frame path: the chains of consecutive passes alternate between the two, so that the chain
+    // of pass p + 1 (three dependent kernels, as long as the tile kernel it has to hide behind) starts beside the chain
+    // of pass p instead of behind it.  Passes share nothing but the targets the tile kernels write (main stream, in order).
+    hipStream_t setup_stream2 = nullptr;
+    bool two_setup_streams = true;
     hipEvent_t ev_setup[RING] = {};
     hipEvent_t ev_tile[RING] = {};
     uint64_t pass_seq = 0;
@@ -541,7 +546,10 @@ int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
 int submit_pending_tiles(tr_scene *s)
 {
     if (s->pending.empty()) return TR_OK;
+    // (each setup stream is in order: its newest pass's event covers the older ones)
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[s->pending.back().p_seq % RING], 0));
+    if (s->two_setup_streams && s->pending.size() > 1u)
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_setup[s->pending[s->pending.size() - 2u].p_seq % RING], 0));
     int status = TR_OK;
     for (const tr_scene::PendingTile &t : s->pending) {
         int st = launch_pending_tile(s, t);
@@ -688,6 +696,7 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
             return tr::fail(TR_E_BIN_OVERFLOW, "the pools of polygon records would exceed 128 GiB");
     }
     HIP_TRY(hipStreamSynchronize(s->setup_stream));
+    HIP_TRY(hipStreamSynchronize(s->setup_stream2));
     s->pool_cap = (uint32_t)cap;
     int st = TR_OK;
     for (int k = 0; k < LOOKAHEAD && st == TR_OK; k++) {
@@ -949,9 +958,9 @@ int run_pass(tr_scene *s, const PassDesc &p)
     // ahead of a fast GPU must keep its overlap: asking the stream instead cost small frames 7-16 %).
     const bool chain_on_main = s->own_stream && s->quiescent && s->pending.empty() && s->group_submitted == s->group_seq;
     s->quiescent = false;
-    hipStream_t chain = chain_on_main ? s->stream : s->setup_stream;
+    hipStream_t chain = chain_on_main ? s->stream : (s->two_setup_streams && (p_seq & 1u)) ? s->setup_stream2 : s->setup_stream;
     if (!chain_on_main && p_seq >= (uint64_t)LOOKAHEAD)
-        HIP_TRY(hipStreamWaitEvent(s->setup_stream, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
+        HIP_TRY(hipStreamWaitEvent(chain, s->ev_tile[(p_seq - LOOKAHEAD) % RING], 0));
     // the chain: vertex stage + counting, work lists + pool ranges, records into the ranges
     if (lit_pass) {  // (first in the chain: it needs nothing but the frame's constants)
         EventPair el = { nullptr, nullptr, K_LIT, 1u };
@@ -1435,6 +1444,7 @@ int finish_groups(tr_scene *s)
     if (s->groups_unfenced) {
         const tr_scene::GroupSet &gs = s->grp[(s->group_submitted + GROUP_SETS - 1) % GROUP_SETS];
         HIP_TRY(hipStreamWaitEvent(s->setup_stream, gs.ev_tile, 0));
+        HIP_TRY(hipStreamWaitEvent(s->setup_stream2, gs.ev_tile, 0));
         s->groups_unfenced = false;
     }
     return TR_OK;
@@ -1682,11 +1692,13 @@ void destroy(tr_scene *s)
     dev_free(s->d_packed);
     for (int k = 0; k < LOOKAHEAD; k++) dev_free(s->d_lit[k]);
     if (s->setup_stream) (void)hipStreamSynchronize(s->setup_stream);
+    if (s->setup_stream2) (void)hipStreamSynchronize(s->setup_stream2);
     for (int k = 0; k < RING; k++) {
         if (s->ev_setup[k]) (void)hipEventDestroy(s->ev_setup[k]);
         if (s->ev_tile[k]) (void)hipEventDestroy(s->ev_tile[k]);
     }
     if (s->setup_stream) (void)hipStreamDestroy(s->setup_stream);
+    if (s->setup_stream2) (void)hipStreamDestroy(s->setup_stream2);
     for (tr_scene::BinState *b : { &s->bin_color, &s->bin_depth }) {
         for (int k = 0; k < SETS; k++) {
             dev_free(b->count[k]);
@@ -1901,6 +1913,8 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         if ((st = dev_alloc(&s->d_recs[k], (size_t)(mesh->n_tri ? mesh->n_tri : 1u) * s->rec_pieces))) return st;
     }
     HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->setup_stream2, hipStreamNonBlocking));
+    s->two_setup_streams = !(getenv("TR_SETUP_STREAMS") && atoi(getenv("TR_SETUP_STREAMS")) == 1);  // experiment hook
     for (int k = 0; k < RING; k++) {
         HIP_TRY(hipEventCreateWithFlags(&s->ev_setup[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_tile[k], hipEventDisableTiming));
