@@ -111,6 +111,138 @@ def self_launch(args, argv):
     raise SystemExit(r.returncode)
 
 
+def pmc_traffic(workload, kernel, frames_in_launch, world=1):
+    """HBM bytes of one launch of `kernel` for `workload` from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    separate passes: profiles/pmc_traffic.json).  Only reported when the counters were collected on THIS source
+    (fingerprint match) and on one GPU.  Returns (bytes or None, note, entry)."""
+    traffic, note, entry = None, "not profiled", {}
+    tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tf):
+        return traffic, note, entry
+    try:
+        db = json.load(open(tf))
+        entry = db.get("workloads", {}).get(workload, {})
+        if world != 1:
+            note = "profiled on one GPU only"
+        elif not entry:
+            note = "workload not profiled"
+        elif db.get("source_fingerprint") != source_fingerprint():
+            note = "profiles/pmc_traffic.json was collected on other source (%s)" % db.get("source_fingerprint")
+        elif kernel in entry.get("per_kernel_hbm_bytes_per_launch", {}) or entry.get("kernel") == kernel:
+            traffic = entry.get("per_kernel_hbm_bytes_per_launch", {}).get(kernel, entry.get("hbm_bytes_per_launch"))
+            note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
+            profiled_frames = entry.get("frames_per_launch", 1)
+            if abs(profiled_frames - frames_in_launch) > 0.05 * frames_in_launch:
+                # (a long run's launches hold more frames than the profiled loop's: the bytes are per
+                # frame -- every frame has targets of its own -- and are scaled to this run's launch)
+                traffic = int(round(traffic / profiled_frames * frames_in_launch))
+                note += "; measured per launch of %s frames, scaled to %.2f" % (profiled_frames, frames_in_launch)
+    except Exception as e:  # a malformed file must not take the bench down
+        traffic, note = None, "unreadable pmc_traffic.json: %s" % e
+    return traffic, note, entry
+
+
+# BASELINE.json `configs`, as bench flags: (label, model, pipeline, size, grid, steps)
+BASELINE_CONFIGS = [
+    ("configs[0]", "african_head", "default", 800, 1, 400),
+    ("configs[1]", "diablo", "phong", 2048, 1, 400),
+    ("configs[2]", "diablo", "darboux", 4096, 1, 200),
+    ("configs[3]", "diablo", "shadow", 4096, 1, 200),
+    ("configs[4]", "diablo", "specular", 8192, 8, 64),
+]
+
+
+def measure_config(T, O, torch, label, model, pipe, size, grid, steps, device_index):
+    """One BASELINE config on one GPU (SURVEY.md 8d "Report"): `steps` frames of the reference's first-frame state
+    through tr_scene_render_frames, timed like the headline (frames resident in HBM, device idle on both sides), the
+    last frame checked against the CPU oracle's, the tile kernel's roofline from the library's own profile of the
+    same frames.  configs[4] is the whole 8192^2 frame on ONE GPU here; its 8-way sharded form is the N > 1 run's
+    `scale_config`."""
+    adir = find_assets(model)
+    if adir:
+        mesh, texs = T.load_assets(adir)
+        wl_model = "%s.obj" % model
+    else:
+        mesh, texs = T.synthetic_scene()
+        wl_model = "synthetic-sphere-5022"
+    if grid > 1:
+        mesh = T.instanced_grid(mesh, grid)
+        wl_model += " x%d grid" % (grid * grid)
+    W = H = size
+    workload = "%s, -s %s, %dx%d" % (wl_model, pipe, W, H)
+    cam, lt = camera(0.0), light(0.0)
+    scene = T.Scene(W, H, mesh, texs, pipe, device=device_index)
+    params = np.zeros((steps, 12), np.float32)
+    params[:, 0:3] = lt
+    params[:, 3:6], params[:, 6:9], params[:, 9:12] = cam
+
+    def idle():
+        scene.flush()
+        try:
+            scene.sync()
+        except T.TinyRendererError:
+            pass
+        torch.cuda.synchronize()
+
+    for attempt in range(3):   # warm-up (again if it is what made the pools grow)
+        scene.render_frames(params[:max(steps // 4, 8)])
+        idle()
+        try:
+            scene.sync()
+            break
+        except T.TinyRendererError as e:
+            if e.code != -9:
+                raise
+    idle()
+    t0 = time.perf_counter()
+    scene.render_frames(params)
+    idle()
+    elapsed = time.perf_counter() - t0
+    status = scene.sync()
+    scene.profile_enable(True)
+    scene.render_frames(params)
+    idle()
+    prof = scene.profile_read()
+    scene.profile_enable(False)
+    gpu_frame = scene.get_frame_buffer()
+    scene.close()
+
+    cpu = O.Scene(W, H, mesh, texs, pipe)
+    cpu.clear()
+    cpu.set_light_direction(lt)
+    cpu.set_camera(*cam)
+    assert cpu.render() == 0
+    stats = cpu.stats()
+    color = stats[1] if pipe in ("shadow", "occlusion") else stats[0]
+    n_shaded = color["frag_accept"]
+    diff = np.abs(gpu_frame.astype(np.int16) - cpu.get_frame_buffer().astype(np.int16))
+    tol = 1 if pipe == "specular" and not T.load_library().tr_specular_exact() else 0
+    cpu.close()
+
+    bytes_by_kernel = algorithmic_bytes(W, H, pipe, stats)
+    dom = max(bytes_by_kernel, key=lambda k: prof.get(k, {}).get("total_ms", 0.0))
+    tile = prof.get(dom)
+    roofline = None
+    if tile and tile["launches"]:
+        avg_s = tile["total_ms"] / tile["launches"] / 1e3
+        frames_in_launch = tile["frames"] / tile["launches"]
+        ach = bytes_by_kernel[dom] * frames_in_launch / avg_s / 1e9
+        traffic, note, _ = pmc_traffic(workload, dom, frames_in_launch)
+        roofline = {"kernel": dom, "frac": round(ach / HBM_PEAK_GBPS, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "physical_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+                    "traffic": traffic, "traffic_source": note,
+                    "avg_launch_us_per_frame": round(avg_s * 1e6 / frames_in_launch, 2),
+                    "algorithmic_bytes_per_frame": sum(bytes_by_kernel.values())}
+    return {"config": label, "workload": workload,
+            "metric": "Mpixels/s shaded (z-test + %s) at %dx%d" % (pipe, W, H),
+            "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 5),
+            "value": round(n_shaded * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
+            "n_shaded_per_frame": n_shaded, "frames_per_s": round(steps / elapsed, 1),
+            "kernel_us_per_frame": {k: round(v["total_ms"] / max(v["frames"], 1) * 1e3, 2) for k, v in prof.items()},
+            "roofline": roofline, "parity_ok": bool(diff.max() <= tol), "max_abs_rgb_diff": int(diff.max()),
+            "device_status": status}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +255,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the orbit / latency / read-back legs (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config report of BASELINE.json's five configs")
     ap.add_argument("--exchange", choices=("rccl", "peer"), default=os.environ.get("TR_BENCH_EXCHANGE", "rccl"),
                     help="N>1: how the bands travel: torch.distributed all_gather (RCCL) or the library's "
                          "peer-to-peer band copies (tr_exchange_*)")
@@ -491,6 +624,7 @@ def main():
         dist.all_gather_object(per_rank, mine)
 
     out = None
+    closed_scene = False
     if rank == 0:
         from oracle import oracle as O
 
@@ -552,32 +686,7 @@ def main():
             frames_in_launch = tile["frames"] / tile["launches"]
             bytes_launch = bytes_alg * frames_in_launch / world
             ach = bytes_launch / avg_s / 1e9
-            traffic, traffic_note, entry = None, "not profiled", {}
-            tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    # HBM bytes of one launch of the dominant kernel from the rocprofv3 PMC passes of this
-                    # workload (FETCH_SIZE x2 + WRITE_SIZE, separate passes).  Only reported when the
-                    # counters were collected on THIS source (fingerprint match) and on one GPU.
-                    db = json.load(open(tf))
-                    entry = db.get("workloads", {}).get(workload, {})
-                    if world != 1:
-                        traffic_note = "profiled on one GPU only"
-                    elif not entry:
-                        traffic_note = "workload not profiled"
-                    elif db.get("source_fingerprint") != source_fingerprint():
-                        traffic_note = "profiles/pmc_traffic.json was collected on other source (%s)" % db.get("source_fingerprint")
-                    elif dom in entry.get("per_kernel_hbm_bytes_per_launch", {}) or entry.get("kernel") == dom:
-                        traffic = entry.get("per_kernel_hbm_bytes_per_launch", {}).get(dom, entry.get("hbm_bytes_per_launch"))
-                        traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, %s" % entry.get("source", "profiles/")
-                        profiled_frames = entry.get("frames_per_launch", 1)
-                        if abs(profiled_frames - frames_in_launch) > 0.05 * frames_in_launch:
-                            # (a long run's launches hold more frames than the profiled loop's: the bytes are per
-                            # frame -- every frame has targets of its own -- and are scaled to this run's launch)
-                            traffic = int(round(traffic / profiled_frames * frames_in_launch))
-                            traffic_note += "; measured per launch of %s frames, scaled to %.2f" % (profiled_frames, frames_in_launch)
-                except Exception as e:  # a malformed file must not take the bench down
-                    traffic, traffic_note = None, "unreadable pmc_traffic.json: %s" % e
+            traffic, traffic_note, entry = pmc_traffic(workload, dom, frames_in_launch, world)
             physical = round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None
             # the kernel's real limiter: what crosses HBM is a fraction of the algorithmic bytes (fast-clear and
             # colour-clean flags), the busy tiles are bound by vector-instruction issue.  issue_frac = share of the
@@ -607,7 +716,9 @@ def main():
                        "frames": int(len(intervals)),
                        "what": "completion-to-completion of consecutive frames' tile kernels (HIP events, profiled loop)"}
         out = {
-            "metric": "Mpixels/s shaded (z-test + Phong) at 4096x4096",
+            # (BASELINE.json's metric string for the workload it is quoted on; any other --size / --pipeline says what it ran)
+            "metric": "Mpixels/s shaded (z-test + Phong) at 4096x4096" if (pipe == "phong" and W == 4096 and H == 4096)
+            else "Mpixels/s shaded (z-test + %s) at %dx%d" % (pipe, W, H),
             "value": round(n_shaded * args.steps / elapsed / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -661,17 +772,34 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        # ---- SURVEY.md 8d "Report": every BASELINE config that fits one GPU, in the same run (default flags only) ----
+        default_run = (world == 1 and not use_dist and extras and not args.no_configs and pipe == "phong" and W == 4096
+                       and args.model == "diablo" and args.grid == 1)
+        if default_run:
+            scene.close()   # (its slots and pools: 5 GB the 8192^2 config should not have to share the device with)
+            closed_scene = True
+            reports = []
+            for label, model, cpipe, csize, cgrid, csteps in BASELINE_CONFIGS:
+                try:
+                    reports.append(measure_config(T, O, torch, label, model, cpipe, csize, cgrid, csteps, device_index))
+                except Exception as e:   # one config must not take the headline down
+                    reports.append({"config": label, "error": "%s: %s" % (type(e).__name__, e)})
+            out["configs"] = reports
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist:
         dist.barrier()
         if exchange is not None:
             exchange.close()
-    (sharded if grouped_dist else scene).close()
+    if not closed_scene:
+        (sharded if grouped_dist else scene).close()
     if use_dist:
         dist.destroy_process_group()
     if out is not None and not out["parity_vs_oracle"]["ok"]:
         raise SystemExit("GPU frame differs from the oracle")
+    if out is not None and any(not c.get("parity_ok", False) for c in out.get("configs", [])):
+        raise SystemExit("a BASELINE config's GPU frame differs from the oracle (or the config failed): %s"
+                         % [c.get("config") for c in out["configs"] if not c.get("parity_ok", False)])
 
 
 if __name__ == "__main__":
