@@ -243,6 +243,101 @@ def measure_config(T, O, torch, label, model, pipe, size, grid, steps, device_in
             "device_status": status}
 
 
+XGMI_LINK_GBPS = 76.8   # one xGMI link, one direction (7 links x ~153 GB/s bidirectional per GPU): the estimate's peak
+
+
+def measure_scale_config(T, torch, dist, args, exchange_kind, rank, world, device_index):
+    """BASELINE.json configs[4] -- "diablo x64 instanced grid, -s specular, 8192x8192, screen-tile shard across the GPUs
+    with the framebuffer all-gather" -- sharded over the ranks of THIS run: every rank renders its row
+    band of a group of frames per kernel launch and the bands are exchanged frame by frame on a second stream
+    (ShardedScene.render_frames).  Collective: every rank calls it; rank 0 returns the report (per-rank device times,
+    bytes exchanged, the assembled frame against the oracle's), the others None."""
+    from tiny_renderer_amd.sharded import ShardedScene
+    adir = find_assets(args.model)
+    if adir:
+        mesh, texs = T.load_assets(adir)
+        wl_model = "%s.obj" % args.model
+    else:
+        mesh, texs = T.synthetic_scene()
+        wl_model = "synthetic-sphere-5022"
+    g = args.scale_grid
+    if g > 1:
+        mesh = T.instanced_grid(mesh, g)
+        wl_model += " x%d grid" % (g * g)
+    W = H = args.scale_size
+    pipe = "specular"
+    workload = "%s, -s %s, %dx%d" % (wl_model, pipe, W, H)
+    cam, lt = camera(0.0), light(0.0)
+    steps = max(args.scale_steps, 1)
+    params = np.zeros((steps, 12), np.float32)
+    params[:, 0:3] = lt
+    params[:, 3:6], params[:, 6:9], params[:, 9:12] = cam
+    s = ShardedScene(W, H, mesh, texs, pipe, device=device_index, exchange=exchange_kind)
+
+    def idle():
+        s.scene.flush()
+        torch.cuda.synchronize()
+
+    s.render_frames(params[:max(steps // 4, 4)])   # warm-up (a pool that has to grow is repaired by sync, on all ranks)
+    idle()
+    s.sync()
+    dist.barrier()
+    sent0 = s.exchange_bytes_sent()
+    t0 = time.perf_counter()
+    s.render_frames(params)
+    idle()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    status = s.sync()
+    sent = s.exchange_bytes_sent()
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    s.scene.profile_enable(True)
+    s.enable_timing(True)
+    s.render_frames(params)
+    idle()
+    prof = s.scene.profile_read()
+    s.scene.profile_enable(False)
+    mine = dict({"rank": rank, "band_rows": list(s.band)}, **s.timings())
+    mine["k_tile_us"] = round(prof["k_tile"]["total_ms"] / max(prof["k_tile"]["frames"], 1) * 1e3, 2) if "k_tile" in prof else None
+    s.sync()
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    band_bytes = (s.band[1] - s.band[0]) * W * 3
+    report = None
+    if rank == 0:
+        from oracle import oracle as O
+        frame = s.last_frame_tensor().cpu().numpy().reshape(H, W, 3)
+        cpu = O.Scene(W, H, mesh, texs, pipe)
+        cpu.clear()
+        cpu.set_light_direction(lt)
+        cpu.set_camera(*cam)
+        assert cpu.render() == 0
+        n_shaded = cpu.stats()[0]["frag_accept"]
+        diff = np.abs(frame.astype(np.int16) - cpu.get_frame_buffer().astype(np.int16))
+        tol = 1 if not T.load_library().tr_specular_exact() else 0
+        cpu.close()
+        report = {"workload": workload, "n_gpus": world, "steps": steps, "exchange": exchange_kind,
+                  "metric": "Mpixels/s shaded (z-test + %s) at %dx%d" % (pipe, W, H),
+                  "ms_per_step": round(elapsed / steps * 1e3, 5), "value": round(n_shaded * steps / elapsed / 1e6, 2),
+                  "unit": "Mpixels/s", "frames_per_s": round(steps / elapsed, 1), "scaling": "strong",
+                  "frames_per_launch": s.scene.frames_per_launch, "per_rank": per_rank,
+                  "exchange_bytes_per_frame": int((sent - sent0) // steps) if sent is not None else int(band_bytes * (world - 1)),
+                  "exchange_dense_bytes_per_frame": int(band_bytes * (world - 1)),
+                  # what the exchange alone costs a frame if every band crosses one xGMI link at its peak: all n - 1
+                  # copies of a band at once over separate links (direct), or handed on link by link (ring)
+                  "exchange_bound_estimate_us": {"direct": round(band_bytes / (XGMI_LINK_GBPS * 1e3), 1),
+                                                 "ring": round(band_bytes * (world - 1) / (XGMI_LINK_GBPS * 1e3), 1),
+                                                 "link_GBps": XGMI_LINK_GBPS,
+                                                 "note": "band bytes / link peak; ranks that share a GPU exchange through its memory, not xGMI"},
+                  "parity_vs_oracle": {"ok": bool(diff.max() <= tol), "max_abs_rgb_diff": int(diff.max()), "tolerance": tol},
+                  "device_status": status}
+    dist.barrier()   # (the others wait while rank 0 compares: nobody tears its slots down under a peer)
+    s.close()
+    return report
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,13 +351,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the orbit / latency / read-back legs (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config report of BASELINE.json's five configs")
-    ap.add_argument("--exchange", choices=("rccl", "peer"), default=os.environ.get("TR_BENCH_EXCHANGE", "rccl"),
-                    help="N>1: how the bands travel: torch.distributed all_gather (RCCL) or the library's "
-                         "peer-to-peer band copies (tr_exchange_*)")
+    ap.add_argument("--exchange", choices=("rccl", "librccl", "peer"), default=os.environ.get("TR_BENCH_EXCHANGE", "rccl"),
+                    help="N>1: how the bands travel: rccl = torch.distributed all_gather_into_tensor (RCCL, the default); "
+                         "librccl = the library's own RCCL communicator (tr_exchange_*, no torch in the data path); peer = the "
+                         "library's peer transport (bands pulled out of IPC-mapped slots by the DMA engines; also runs with "
+                         "several ranks on ONE GPU: TR_BENCH_SHARE_GPU=1)")
     ap.add_argument("--sparse", action="store_true",
                     help="N>1 with --exchange peer: send the band tile by tile, skipping tiles that are the cleared colour on "
                          "both sides (tr_exchange_all_gather_tiles)")
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the render stream (no double buffering)")
+    ap.add_argument("--no-scale", action="store_true", help="N>1: skip the scale_config leg (BASELINE configs[4] sharded N ways)")
+    ap.add_argument("--scale-size", type=int, default=8192, help="scale_config: frame size (BASELINE configs[4]: 8192)")
+    ap.add_argument("--scale-grid", type=int, default=8, help="scale_config: n x n instances of the model (configs[4]: 8)")
+    ap.add_argument("--scale-steps", type=int, default=32, help="scale_config: frames in its timed call")
     ap.add_argument("--submit", choices=("frames", "frame"), default="frames",
                     help="N=1: frames = tr_scene_render_frames (groups of frames per launch), frame = four calls per frame")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="tr_options.frames_per_launch (0 = automatic)")
@@ -285,8 +385,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    if world > 1 and torch.cuda.device_count() < world and os.environ.get("TR_BENCH_SHARE_GPU") != "1":
+    shared_gpu = world > torch.cuda.device_count()
+    if shared_gpu and os.environ.get("TR_BENCH_SHARE_GPU") != "1":
         raise SystemExit("%d ranks but %d GPUs visible" % (world, torch.cuda.device_count()))
+    if shared_gpu and args.exchange != "peer":
+        # (RCCL refuses a communicator with two ranks on one device -- "Duplicate GPU detected" from deep inside
+        # init_process_group; say it here, in one sentence)
+        raise SystemExit("bench.py: %d ranks on %d GPU(s): RCCL needs a device per rank -- rehearse several ranks on one GPU "
+                         "with --exchange peer (the library's peer transport), or give every rank a GPU"
+                         % (world, torch.cuda.device_count()))
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     # TR_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, band scene, double-buffered
@@ -298,7 +405,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        backend = "nccl" if args.exchange == "rccl" else "gloo"  # the peer exchange only needs a rendezvous
+        backend = "nccl" if args.exchange == "rccl" else "gloo"  # the library's exchanges only need a rendezvous
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -306,6 +413,8 @@ def main():
         group_ranks = dist.get_world_size()
         if group_ranks != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus says %d" % (group_ranks, args.gpus))
+    # ShardedScene's name for the transport
+    exchange_kind = {"rccl": "torch", "librccl": "rccl", "peer": "peer-sparse" if args.sparse else "peer"}[args.exchange]
 
     import tiny_renderer_amd as T
 
@@ -329,121 +438,39 @@ def main():
 
     # ---- the scene on this rank -------------------------------------------------------------
     # N = 1: the library's own stream (its frame pipelining hands tile kernels over in batches there)
-    #        and one frame buffer.
-    # N > 1: the scene renders on a real torch side stream (never the null stream: tr_options.stream
-    #        = NULL means a library-owned stream, and a collective on torch's current stream would not
-    #        be ordered behind it) into one of two frame tensors; the exchange of frame f runs on a
-    #        second stream, ordered by events, under the render of frame f + 1.
-    n_buf = 1 if (not use_dist or args.no_overlap) else 2
-    render_stream = comm_stream = None
-    band = None
-    exchange = None
-    if use_dist:
-        render_stream = torch.cuda.Stream()
-        comm_stream = render_stream if args.no_overlap else torch.cuda.Stream()
-        if render_stream.cuda_stream == 0:
-            raise SystemExit("the render stream must not be the null stream")
-        band = T.band_rows(H, world, rank)
-        if len({T.band_rows(H, world, r)[1] - T.band_rows(H, world, r)[0] for r in range(world)}) != 1:
-            raise SystemExit("frame height must divide by the number of GPUs (in-place all-gather)")
-    if use_dist and args.exchange == "peer":
-        # the library's exchange owns the frame slots (they are exported to the other ranks through HIP IPC)
-        exchange = T.PeerExchange(n_buf, H * W * 3, rank, world, device_index)
-        fbs = None
-        fb_ptr = [exchange.frame_ptr(b) for b in range(n_buf)]
-    elif use_dist:
-        fbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-        fb_ptr = [fb.data_ptr() for fb in fbs]
-    else:
-        fbs, fb_ptr = None, [None]  # N = 1: the scene's own frame slots
+    #        and its own frame slots.
+    # N > 1: a ShardedScene (tiny_renderer_amd/sharded.py): this rank's band scene on a real torch side stream
+    #        (never the null stream: tr_options.stream = NULL means a library-owned stream, and a collective on
+    #        torch's current stream would not be ordered behind it), double-buffered frame slots, the exchange
+    #        of frame f on a second stream under the render of frame f + 1 -- whichever transport moves the bands.
     torch.cuda.synchronize()
     free_before_scene = torch.cuda.mem_get_info(device_index)[0]
-    grouped = (not use_dist) and args.submit == "frames"
-    # N > 1 through RCCL: every rank renders its band of a GROUP of frames per kernel launch and the bands are
-    # exchanged frame by frame on a second stream while the next group renders (ShardedScene.render_frames)
-    grouped_dist = use_dist and args.exchange == "rccl" and not args.no_overlap and args.submit == "frames"
+    grouped = args.submit == "frames"
     sharded = None
-    if grouped_dist:
-        from tiny_renderer_amd.sharded import ShardedScene
-        sharded = ShardedScene(W, H, mesh, texs, pipe, device=device_index, frames_per_launch=args.frames_per_launch)
-    scene = sharded.scene if grouped_dist else T.Scene(W, H, mesh, texs, pipe, device=device_index,
-                    stream=render_stream.cuda_stream if use_dist else None,
-                    frame_buffer_device=fb_ptr[0] if use_dist else None, band_rows=band,
-                    frames_per_launch=args.frames_per_launch,
-                    trust_frame_buffers=use_dist)   # (the frame tensors are written by this scene and the exchange only)
-    frames_per_launch = scene.frames_per_launch if (grouped or grouped_dist) else 1
-    chunks = None
-    band_bytes = 0
+    band, band_bytes = None, 0
     if use_dist:
+        from tiny_renderer_amd.sharded import ShardedScene
+        sharded = ShardedScene(W, H, mesh, texs, pipe, device=device_index, exchange=exchange_kind,
+                               frames_per_launch=args.frames_per_launch)
+        scene = sharded.scene
+        band = sharded.band
         band_bytes = (band[1] - band[0]) * W * 3
-        if fbs is not None:
-            chunks = [fb[rank * band_bytes:(rank + 1) * band_bytes] for fb in fbs]
+    else:
+        scene = T.Scene(W, H, mesh, texs, pipe, device=device_index, frames_per_launch=args.frames_per_launch)
+    frames_per_launch = scene.frames_per_launch if grouped else 1
 
-    def read_frame(b):
-        if grouped_dist:
+    def read_frame():
+        if use_dist:
             return sharded.last_frame_tensor().cpu().numpy().reshape(H, W, 3)
-        if not use_dist:
-            return scene.get_frame_buffer()
-        if exchange is not None:
-            return exchange.read(b, H, W)
-        return fbs[b].cpu().numpy().reshape(H, W, 3)
+        return scene.get_frame_buffer()
 
-    rendered = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
-    gathered = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
-    gather_started = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
-    render_started = [torch.cuda.Event(enable_timing=True) for _ in range(n_buf)] if use_dist else None
-    frame_no = [0]
-    timing = {"on": False, "render_ms": [], "gather_ms": [], "timed": [False] * n_buf}
-
-    def collect_times(b):
-        # per-rank device times of the frame that last used slot b (its events have completed or are
-        # about to: the render stream is made to wait for `gathered[b]` anyway)
-        if timing["timed"][b]:
-            gathered[b].synchronize()
-            timing["render_ms"].append(render_started[b].elapsed_time(rendered[b]))
-            timing["gather_ms"].append(gather_started[b].elapsed_time(gathered[b]))
-            timing["timed"][b] = False
+    driver = sharded if use_dist else scene
 
     def step(cam_now=cam):
-        if grouped_dist:
-            sharded.clear()
-            sharded.set_light_direction(lt)
-            sharded.set_camera(*cam_now)
-            sharded.render()
-            return
-        if not use_dist:
-            scene.clear()
-            scene.set_light_direction(lt)
-            scene.set_camera(*cam_now)
-            scene.render()
-            return
-        b = frame_no[0] % n_buf
-        frame_no[0] += 1
-        collect_times(b)
-        with torch.cuda.stream(render_stream):
-            if frame_no[0] > n_buf:
-                render_stream.wait_event(gathered[b])  # the exchange of the frame that used this buffer is done
-            if timing["on"]:
-                render_started[b].record(render_stream)   # timing events only in the profiled leg: every event
-            scene.set_frame_buffer_device(fb_ptr[b])      # packet in a queue costs a few microseconds
-            scene.clear()
-            scene.set_light_direction(lt)
-            scene.set_camera(*cam_now)
-            scene.render()  # a caller's stream receives the frame's kernels before render() returns
-            rendered[b].record(render_stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(rendered[b])
-            if timing["on"]:
-                gather_started[b].record(comm_stream)
-            if exchange is not None:
-                if args.sparse:
-                    exchange.all_gather_tiles(b, scene.band_tiles(fb_ptr[b]), comm_stream.cuda_stream)
-                else:
-                    exchange.all_gather(b, rank * band_bytes, band_bytes, comm_stream.cuda_stream)
-            else:
-                dist.all_gather_into_tensor(fbs[b], chunks[b])
-            gathered[b].record(comm_stream)
-        timing["timed"][b] = timing["on"]
+        driver.clear()
+        driver.set_light_direction(lt)
+        driver.set_camera(*cam_now)
+        driver.render()
 
     def frame_params(cams):
         out = np.zeros((len(cams), 12), np.float32)
@@ -455,12 +482,9 @@ def main():
     headline_params = frame_params([cam] * max(args.steps, args.warmup, 1))
 
     def run(k, cams=None, per_frame=False):
-        """k steps.  Grouped submission: ONE tr_scene_render_frames call for all of them."""
-        if grouped_dist and not per_frame:
-            sharded.render_frames(headline_params[:k] if cams is None else frame_params(cams))
-            return
+        """k steps.  Grouped submission: ONE render_frames call for all of them."""
         if grouped and not per_frame:
-            scene.render_frames(headline_params[:k] if cams is None else frame_params(cams))
+            driver.render_frames(headline_params[:k] if cams is None else frame_params(cams))
             return
         for i in range(k):
             step(cam if cams is None else cams[i])
@@ -481,24 +505,19 @@ def main():
                 pass
         torch.cuda.synchronize()  # then wait for every stream of the device
 
-    from tiny_renderer_amd.sharded import any_rank
 
     def clean_sync():
-        """scene.sync() on every rank; True when no rank's triangle bins overflowed (the library has
-        grown them by then).  Taken together: a rank that repeated a loop on its own would issue more
-        collectives than its peers."""
-        overflow = False
-        if grouped_dist:
-            # (collective, and repairs an overflow itself by rendering the last group again on every rank)
-            st = sharded.sync()
-            return True, st
+        """sync on every rank; True when no rank's triangle bins overflowed (the library has grown them by
+        then).  Taken together: a rank that repeated a loop on its own would issue more collectives than its peers."""
+        if use_dist:
+            # (collective, and repairs an overflow itself by rendering the last frame / group again on every rank)
+            return True, sharded.sync()
         try:
-            st = scene.sync()
+            return True, scene.sync()
         except T.TinyRendererError as e:
             if e.code != -9:
                 raise
-            overflow, st = True, e.code
-        return (not any_rank(overflow)), st
+            return False, e.code
 
     for attempt in range(4):   # warm-up; again if it is what made the bins grow
         run(args.warmup)
@@ -508,18 +527,17 @@ def main():
             break
     barrier()
     device_idle()
-    sent_before = exchange.bytes_sent() if exchange is not None else 0
+    sent_before = sharded.exchange_bytes_sent() if use_dist else None
     t0 = time.perf_counter()
     run(args.steps)
     device_idle()   # this rank's frames are complete (flush + torch.cuda.synchronize()) ...
     barrier()       # ... and so are everybody's: the clock stops at the slowest rank (max over ranks below)
     elapsed = time.perf_counter() - t0
     # what this rank really pushed to its peers per frame of the timed loop (the library's count; dense: the band to each)
-    sent_per_frame = (exchange.bytes_sent() - sent_before) // max(args.steps, 1) if exchange is not None else None
+    sent_per_frame = (sharded.exchange_bytes_sent() - sent_before) // max(args.steps, 1) if sent_before is not None else None
     ok, status = clean_sync()
     if not ok:
         raise SystemExit("triangle bins overflowed inside the timed region: the timing is void")
-    last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -549,7 +567,7 @@ def main():
     # (a) as the library runs it by default: frames nobody reads in between are held back and fused;
     # (b) with that switched off (TR_OPT_NO_AUTO_GROUP): one launch of each kernel per frame -- round 1's path
     per_frame_elapsed, per_frame_steps, unfused_elapsed = None, min(args.steps, 500), None
-    if extras and grouped:
+    if extras and grouped and not use_dist:
         run(50, per_frame=True)
         device_idle()
         t1 = time.perf_counter()
@@ -575,9 +593,7 @@ def main():
             device_idle()
             t1 = time.perf_counter()
             step()
-            if use_dist:
-                torch.cuda.synchronize()
-            (sharded if grouped_dist else scene).sync()
+            driver.sync()
             lat.append((time.perf_counter() - t1) * 1e6)
         lat.sort()
         latency_us = {"median": round(lat[len(lat) // 2], 1), "min": round(lat[0], 1)}
@@ -602,24 +618,19 @@ def main():
     # ---- per-kernel device time of the same steps, HIP events on the kernels' own dispatches ----------
     # (ends on the headline frame: the parity check below reads it)
     scene.profile_enable(True)
-    timing["on"] = use_dist
+    if use_dist:
+        sharded.enable_timing(True)
     run(min(args.steps, 400) if use_dist else args.steps)
     device_idle()
-    timing["on"] = False
-    for b in range(n_buf if use_dist else 0):
-        collect_times(b)
     prof = scene.profile_read()
     intervals = np.sort(scene.profile_frame_intervals())
     scene.profile_enable(False)
-    last_buf = (frame_no[0] - 1) % n_buf if use_dist else 0
 
     per_rank = None
     if use_dist:
-        mine = {"rank": rank, "band_rows": list(band),
-                "render_us": round(float(np.median(timing["render_ms"])) * 1e3, 2) if timing["render_ms"] else None,
-                "gather_us": round(float(np.median(timing["gather_ms"])) * 1e3, 2) if timing["gather_ms"] else None,
-                "k_tile_us": round(prof["k_tile"]["total_ms"] / max(prof["k_tile"]["frames"], 1) * 1e3, 2)
-                if "k_tile" in prof else None}
+        mine = dict({"rank": rank, "band_rows": list(band)}, **sharded.timings())
+        mine["k_tile_us"] = round(prof["k_tile"]["total_ms"] / max(prof["k_tile"]["frames"], 1) * 1e3, 2) if "k_tile" in prof else None
+        sharded.enable_timing(False)
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
@@ -640,7 +651,7 @@ def main():
         stats = cpu.stats()
         color = stats[1] if pipe in ("shadow", "occlusion") else stats[0]
         n_shaded = color["frag_accept"]
-        gpu_frame = read_frame(last_buf)
+        gpu_frame = read_frame()
         ref_frame = cpu.get_frame_buffer()
         diff = np.abs(gpu_frame.astype(np.int16) - ref_frame.astype(np.int16))
         # specular calls powf: exact when the library reproduces the host libm's (tr_specular_exact), else 1 LSB
@@ -732,12 +743,15 @@ def main():
                        "polygons": int(mesh["idx"].shape[0]),
                        "submission": ("tr_scene_render_frames: %d frames per launch of each kernel (the later groups of a call "
                                       "of sixteen groups or more grow to 32), every frame into render targets of its own"
-                                      % frames_per_launch) if (grouped or grouped_dist)
+                                      % frames_per_launch) if grouped
                        else "per frame: clear, set_light_direction, set_camera, render",
                        "frames_per_launch": frames_per_launch,
-                       "sharding": ("screen row bands (tr_band_rows) + %s of the framebuffer%s" % (
-                           "RCCL all-gather" if exchange is None else "peer-to-peer band copies (tr_exchange)",
-                           "" if args.no_overlap else ", double-buffered: exchange of frame f under the render of f+1"))
+                       "sharding": ("screen row bands (tr_band_rows) + %s of the framebuffer, double-buffered: exchange of frame f "
+                                    "under the render of f+1" % {
+                                        "torch": "RCCL all-gather (torch.distributed)",
+                                        "rccl": "RCCL all-gather (the library's own communicator, tr_exchange)",
+                                        "peer": "peer-to-peer band copies (tr_exchange: bands pulled by the DMA engines)",
+                                        "peer-sparse": "peer-to-peer sparse tile push (tr_exchange_all_gather_tiles)"}[exchange_kind])
                        if use_dist else "none"},
             "group_ranks": group_ranks if use_dist else 1,
             # what rank 0 ships per frame: its band to each of the others (--exchange peer: the library's count of the timed
@@ -785,18 +799,23 @@ def main():
                 except Exception as e:   # one config must not take the headline down
                     reports.append({"config": label, "error": "%s: %s" % (type(e).__name__, e)})
             out["configs"] = reports
+    if not closed_scene:
+        driver.close()
+    scale = None
+    if use_dist and world > 1 and not args.no_scale:
+        scale = measure_scale_config(T, torch, dist, args, exchange_kind, rank, world, device_index)
+    if out is not None:
+        if scale is not None:
+            out["scale_config"] = scale
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist:
         dist.barrier()
-        if exchange is not None:
-            exchange.close()
-    if not closed_scene:
-        (sharded if grouped_dist else scene).close()
-    if use_dist:
         dist.destroy_process_group()
     if out is not None and not out["parity_vs_oracle"]["ok"]:
         raise SystemExit("GPU frame differs from the oracle")
+    if out is not None and out.get("scale_config") and not out["scale_config"]["parity_vs_oracle"]["ok"]:
+        raise SystemExit("scale_config: the assembled frame differs from the oracle")
     if out is not None and any(not c.get("parity_ok", False) for c in out.get("configs", [])):
         raise SystemExit("a BASELINE config's GPU frame differs from the oracle (or the config failed): %s"
                          % [c.get("config") for c in out["configs"] if not c.get("parity_ok", False)])

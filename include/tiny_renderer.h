@@ -217,7 +217,7 @@ int tr_scene_set_frame_buffer_device(tr_scene *s, void *frame_buffer_device);
 int tr_band_rows(uint32_t height, uint32_t n_ranks, uint32_t rank, uint32_t *row0, uint32_t *row1);
 
 /* Multi-GPU frame exchange without RCCL (SURVEY.md 8e's hand-tuned alternative; nothing of the kind
- * upstream).  One process per GPU.  Each rank creates its end -- one or two full-size frame buffers
+ * upstream).  One process per GPU.  Each rank creates its end -- 1 to 64 full-size frame buffers
  * ("slots": pass their device pointers to tr_scene_create / tr_scene_set_frame_buffer_device) -- and
  * publishes a TR_EXCHANGE_HANDLE_BYTES record; once every rank has connected to all records (in rank
  * order; the host's own rendezvous carries them), tr_exchange_all_gather(slot, offset, bytes, stream)
@@ -246,6 +246,13 @@ void *tr_exchange_frame(tr_exchange *x, uint32_t slot);
 int tr_exchange_export(tr_exchange *x, void *record /* TR_EXCHANGE_HANDLE_BYTES */);
 int tr_exchange_connect(tr_exchange *x, const void *records /* n_ranks * TR_EXCHANGE_HANDLE_BYTES */);
 int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, void *hip_stream);
+/* Declares every rank's byte range of a frame (n_ranks offsets and sizes, disjoint: the bands of tr_band_rows), the same
+ * on all ranks, before the first tr_exchange_all_gather.  The peer transport's dense exchange then PULLS: a rank copies
+ * its peers' ranges out of their mapped slots into its own slot, and nothing but 4-byte flags is ever written into
+ * another rank's memory -- a peer that is late or gone costs this rank its own frame (TR_E_EXCHANGE), never a slot the
+ * owner had not opened (the push form's copy engines cannot be predicated on the error word).  tr_exchange_all_gather
+ * must then be called with this rank's declared range.  NULL, NULL: back to the push form.  RCCL transport: checked, unused. */
+int tr_exchange_set_ranges(tr_exchange *x, const size_t *offsets, const size_t *bytes);
 /* The SPARSE form of the exchange: the band of `slot`'s frame that scene `s` renders goes to the peers tile by tile
  * (128 x 16 pixels), and a tile that holds the cleared colour here AND held it the last time this rank wrote the
  * peer's copy does not travel at all -- three quarters of a 4096x4096 frame of the reference's model.  The scene

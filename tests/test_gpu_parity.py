@@ -1042,6 +1042,45 @@ def test_sharded_scene_render_frames(built):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("exchange", ["peer", "peer-sparse"])
+def test_sharded_scene_two_ranks_one_gpu(built, exchange):
+    """The multi-rank path with a REAL peer: two rank processes of a ShardedScene share this box's one GPU (RCCL refuses two
+    ranks on one device, so the bands travel through the library's peer transport -- dense: pulled by the DMA engines;
+    sparse: the product's k_push_tiles) through render, render_frames, the collective repair of a bin overflow that only
+    ONE rank had, and an error in ONE band that every rank must raise; the assembled frame is compared with the oracle's
+    on BOTH ranks: tests/sharded_ranks_worker.py."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(H.REPO, "tests", "sharded_ranks_worker.py"), exchange],
+                       env=env, cwd=H.REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rank 0 OK" in r.stdout and "rank 1 OK" in r.stdout, (r.stdout[-1500:] + r.stderr[-4000:])
+
+
+def test_two_ranks_on_one_gpu_under_rccl_says_so(built):
+    """`bench.py --gpus 2` with both ranks on this box's one GPU and the default (RCCL) exchange: one clear sentence, not
+    RCCL's "Duplicate GPU detected" from the bottom of a traceback."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--size", "512", "--steps", "4", "--warmup", "2",
+                        "--no-cpu"], env=env, cwd=H.REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "RCCL needs a device per rank" in r.stderr and "--exchange peer" in r.stderr, r.stderr[-2000:]
+    assert "Duplicate GPU" not in r.stderr
+
+
 def test_rccl_exchange_behind_the_c_abi(built):
     """The RCCL backend of tr_exchange_* (the library owns the communicator: SURVEY.md 8b / 8e) with one rank, in
     its own process and without torch: tests/rccl_exchange_worker.py."""
@@ -1072,8 +1111,8 @@ def test_peer_exchange_two_processes_one_gpu(diablo, sparse):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--exchange", "peer", "--size", "1024",
-                        "--steps", "40", "--warmup", "5", "--no-cpu"] + (["--sparse"] if sparse else []), env=env, cwd=H.REPO, capture_output=True,
-                       text=True, timeout=420)
+                        "--steps", "40", "--warmup", "5", "--no-cpu", "--scale-size", "2048", "--scale-grid", "4", "--scale-steps", "12"]
+                       + (["--sparse"] if sparse else []), env=env, cwd=H.REPO, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -1088,18 +1127,31 @@ def test_peer_exchange_two_processes_one_gpu(diablo, sparse):
         assert 0 < j["exchange_bytes_per_frame"] < dense // 2, j["exchange_bytes_per_frame"]
     else:
         assert j["exchange_bytes_per_frame"] == dense
+    # BASELINE configs[4]'s shape (an n x n grid of the model, specular) sharded over the same two ranks, beside the headline
+    sc = j["scale_config"]
+    assert sc["n_gpus"] == 2 and sc["parity_vs_oracle"]["ok"] and "x16 grid" in sc["workload"] and "2048x2048" in sc["workload"]
+    assert len(sc["per_rank"]) == 2 and all(r_["render_us"] and r_["gather_us"] and r_["k_tile_us"] for r_ in sc["per_rank"])
+    assert sc["exchange_bound_estimate_us"]["direct"] > 0 and sc["exchange_dense_bytes_per_frame"] == 1024 * 2048 * 3
 
 
 def _exchange_rank(rank, q_in, q_out, participate):
     import ctypes as C
     import os
     os.environ["TR_EXCHANGE_TIMEOUT_MS"] = "1500"
+    import torch
     import tiny_renderer_amd as T
     from tiny_renderer_amd._lib import TR_EXCHANGE_HANDLE_BYTES
+    from tiny_renderer_amd.sharded import _DeviceBytes
     L = T.load_library()
     h = C.c_void_p()
     n = 1 << 20
     assert L.tr_exchange_create(0, 2, rank, 1, n, C.byref(h)) == 0
+    # every rank's half of the frame is known to everybody: the dense exchange pulls (nothing but flags crosses into a peer)
+    off, siz = (C.c_size_t * 2)(0, n // 2), (C.c_size_t * 2)(n // 2, n // 2)
+    assert L.tr_exchange_set_ranges(h, off, siz) == 0
+    slot = torch.as_tensor(_DeviceBytes(L.tr_exchange_frame(h, 0), n), device="cuda:0")
+    slot[rank * (n // 2):(rank + 1) * (n // 2)] = 7 + rank          # this rank's band: sevens / eights
+    torch.cuda.synchronize()
     rec = C.create_string_buffer(TR_EXCHANGE_HANDLE_BYTES)
     assert L.tr_exchange_export(h, rec) == 0
     q_out.put((rank, bytes(rec.raw)))
@@ -1111,13 +1163,21 @@ def _exchange_rank(rank, q_in, q_out, participate):
         out = (C.c_uint8 * n)()
         code = L.tr_exchange_read(h, 0, out, n)
     q_out.put(("done", rank, code))
-    q_in.get(timeout=120)   # stay alive (mappings valid) until told to leave
+    q_in.get(timeout=120)   # stay alive (mappings valid) until told to leave: by now the other rank has given up
+    torch.cuda.synchronize()
+    mine = slot.cpu().numpy()
+    other = mine[(1 - rank) * (n // 2):(2 - rank) * (n // 2)]
+    # the rank that never joined: the half of ITS slot that belongs to the peer is as it was created (zeros) -- the
+    # peer's copy engines wrote nothing into a slot its owner had not opened
+    untouched = bool((other == 0).all()) if not participate else None
+    q_out.put(("slot", rank, untouched))
     L.tr_exchange_destroy(h)
 
 
 def test_peer_exchange_reports_a_missing_rank(built):
     """A rank whose peer never joins the all-gather must not hang the GPU: the device-side waits give up
-    (TR_EXCHANGE_TIMEOUT_MS = 1.5 s here, ten seconds by default) and the status is TR_E_EXCHANGE."""
+    (TR_EXCHANGE_TIMEOUT_MS = 1.5 s here, ten seconds by default) and the status is TR_E_EXCHANGE -- and, the ranges
+    being declared (tr_exchange_set_ranges: the pull form), the absent rank's slot is left exactly as it was."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue()
@@ -1134,8 +1194,14 @@ def test_peer_exchange_reports_a_missing_rank(built):
         done[rank] = code
     for q in q_ins:
         q.put("leave")
+    slots = {}
+    for _ in range(2):
+        tag, rank, untouched = q_out.get(timeout=180)
+        assert tag == "slot"
+        slots[rank] = untouched
     for p in procs:
         p.join(60)
     assert done[0] == -11, done    # TR_E_EXCHANGE on the rank that waited alone
     assert done[1] == 0
+    assert slots[1] is True, "the absent rank's slot was written by its peer"
     assert all(p.exitcode == 0 for p in procs)

@@ -123,6 +123,7 @@ SYMBOLS = {
     "tr_exchange_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tr_exchange_all_gather": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "tr_exchange_set_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tr_exchange_all_gather_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(BandTiles), C.c_void_p]),
     "tr_scene_band_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BandTiles)]),
     "tr_exchange_status": (C.c_int, [C.c_void_p]),

@@ -32,6 +32,10 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=-1)
     ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of -p")
     ap.add_argument("--gpus", type=int, default=1, help="shard every frame by screen rows over this many GPUs")
+    ap.add_argument("--exchange", choices=("torch", "rccl", "peer", "peer-sparse"), default="torch",
+                    help="--gpus N: how the bands travel (ShardedScene): torch = RCCL all-gather through torch.distributed, rccl = "
+                         "the library's own RCCL communicator, peer / peer-sparse = the library's peer transport (these two also "
+                         "run with several ranks on one GPU)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -75,17 +79,25 @@ def main(argv=None):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        n_dev = torch.cuda.device_count()
+        if world > n_dev and not args.exchange.startswith("peer"):
+            raise SystemExit("%d ranks on %d GPU(s): RCCL needs a device per rank -- use --exchange peer to run several ranks "
+                             "on one GPU" % (world, n_dev))
+        local %= max(n_dev, 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.exchange == "torch":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")   # (the library's exchanges only need a rendezvous for their records)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
-        scene = ShardedScene(args.width, args.height, mesh, texs, args.pipeline, device=local)
+        scene = ShardedScene(args.width, args.height, mesh, texs, args.pipeline, device=local, exchange=args.exchange)
     else:
         scene = T.Scene(args.width, args.height, mesh, texs, args.pipeline, device=args.device)
     rc = _run(args, T, scene, sharded, rank, say)
     if sharded:
         import torch.distributed as dist
-        scene.close()
+        scene.close()   # (collective: nobody unmaps a slot a peer may still be reading)
         dist.barrier()
         dist.destroy_process_group()
     return rc

@@ -1,8 +1,8 @@
 // tr_exchange.cpp -- the hand-tuned alternative to the RCCL all-gather of the frame buffer
 // ("7 concurrent peer copies ... measure both").
 //
-// One process per GPU.  Every rank owns one or two full-size frame buffers ("slots") in device
-// memory and exports them (hipIpcGetMemHandle); after the handles have been exchanged -- by
+// One process per GPU.  Every rank owns up to 64 full-size frame buffers ("slots": one device
+// allocation) and exports them (hipIpcGetMemHandle); after the handles have been exchanged -- by
 // whatever rendezvous the host has: torch.distributed in bench.py -- every rank holds all its
 // peers' slots mapped.  An all-gather of slot b is then, on rank r:
 //
@@ -12,6 +12,14 @@
 //      copies run beside the next frame's tile kernel, which an RCCL kernel cannot: a machine-filling
 //      kernel starves another queue's workgroups, profiles/r02_notes.md), then store "arrived, g"
 //   3. on the caller's stream: join the copy streams, wait until every peer's "arrived" says g
+//
+// That is the PUSH form, for callers whose ranges differ from call to call.  A copy engine cannot be predicated on
+// the error word: after a wait has timed out the push still lands in a slot its owner never opened.  Once the ranks'
+// byte ranges are known to everybody (tr_exchange_set_ranges: tr_band_rows' bands) the dense exchange therefore PULLS:
+// 1. "my band of generation g is ready" to every peer; 2. per peer p: wait for p's "ready", copy p's band out of p's
+// mapped slot into the OWN slot, tell p "pulled, g"; 3. wait until every peer has pulled.  Nothing but 4-byte flags
+// is ever written into another rank's memory: a peer that is late or gone costs this rank its own frame (error word)
+// and nobody else anything.  The sparse tile push (k_push_tiles) is a kernel and is predicated.
 //
 // Flags are generation counters in uncached device memory (hipDeviceMallocUncached), written across
 // GPUs by one-lane kernels with system-scope stores and awaited by one-lane-per-flag kernels that spin
@@ -49,7 +57,7 @@
     } while (0)
 
 namespace {
-constexpr uint32_t MAX_SLOTS = 2;
+constexpr uint32_t MAX_SLOTS = 64;
 constexpr uint32_t MAX_RANKS = 64;
 
 // what a rank publishes
@@ -58,7 +66,7 @@ struct Blob {
     uint64_t frame_bytes;
     union {
         struct {
-            hipIpcMemHandle_t frame[MAX_SLOTS];
+            hipIpcMemHandle_t frames;  // all slots: one allocation, slot b at b * slot_stride
             hipIpcMemHandle_t flags;
         };
         ncclUniqueId rccl_id;  // TR_EXCHANGE_RCCL: rank 0's record carries the communicator's id
@@ -116,8 +124,11 @@ struct FlagIndex {
 struct tr_exchange {
     int device = 0;
     uint32_t n_ranks = 0, rank = 0, n_slots = 0;
-    size_t frame_bytes = 0;
+    size_t frame_bytes = 0, slot_stride = 0;
+    uint8_t *frames = nullptr;              // the slots' allocation
     uint8_t *frame[MAX_SLOTS] = {};
+    std::vector<uint8_t *> peer_base;       // [rank]: the peer's allocation mapped here
+    std::vector<size_t> range_offset, range_bytes;  // tr_exchange_set_ranges: every rank's part of a frame (pull form)
     uint32_t *flags = nullptr;              // this rank's block (peers write into it)
     std::vector<uint8_t *> peer_frame[MAX_SLOTS];  // [slot][rank], own entry = own pointer
     std::vector<uint32_t *> peer_flags;            // [rank]
@@ -158,7 +169,7 @@ int tr_exchange_create_backend(int device, uint32_t n_ranks, uint32_t rank, uint
         if (st != TR_OK) return st;
     }
     if (n_ranks == 0 || n_ranks > MAX_RANKS || rank >= n_ranks || n_slots == 0 || n_slots > MAX_SLOTS || frame_bytes == 0)
-        return tr::fail(TR_E_INVALID, "tr_exchange_create: need rank < n_ranks <= 64, 1..2 slots, a non-empty frame");
+        return tr::fail(TR_E_INVALID, "tr_exchange_create: need rank < n_ranks <= 64, 1..64 slots, a non-empty frame");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipGetDevice(&device));
     tr_exchange *x = new tr_exchange();
@@ -172,11 +183,10 @@ int tr_exchange_create_backend(int device, uint32_t n_ranks, uint32_t rank, uint
         const long v = atol(ms);
         if (v > 0) x->timeout_ticks = (uint64_t)v * 100000ull;
     }
-    hipError_t e = hipSuccess;
-    for (uint32_t b = 0; b < n_slots && e == hipSuccess; b++) {
-        e = hipMalloc((void **)&x->frame[b], frame_bytes);
-        if (e == hipSuccess) e = hipMemset(x->frame[b], 0, frame_bytes);
-    }
+    x->slot_stride = (frame_bytes + 4095u) & ~(size_t)4095u;
+    hipError_t e = hipMalloc((void **)&x->frames, x->slot_stride * n_slots);
+    if (e == hipSuccess) e = hipMemset(x->frames, 0, x->slot_stride * n_slots);
+    for (uint32_t b = 0; b < n_slots && e == hipSuccess; b++) x->frame[b] = x->frames + (size_t)b * x->slot_stride;
     if (e == hipSuccess) e = hipExtMallocWithFlags((void **)&x->flags, FlagIndex::words() * 4, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(x->flags, 0, FlagIndex::words() * 4);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&x->fork, hipEventDisableTiming);
@@ -213,7 +223,7 @@ int tr_exchange_export(tr_exchange *x, void *blob)
         b.magic = 0x54525243u;  // "TRRC"
         b.rccl_id = x->rccl_id;  // (meaningful in rank 0's record only)
     } else {
-        for (uint32_t s = 0; s < x->n_slots; s++) HIP_TRY(hipIpcGetMemHandle(&b.frame[s], x->frame[s]));
+        HIP_TRY(hipIpcGetMemHandle(&b.frames, x->frames));
         HIP_TRY(hipIpcGetMemHandle(&b.flags, x->flags));
     }
     memset(blob, 0, TR_EXCHANGE_HANDLE_BYTES);
@@ -244,6 +254,7 @@ int tr_exchange_connect(tr_exchange *x, const void *blobs)
     }
     for (uint32_t s = 0; s < x->n_slots; s++) x->peer_frame[s].assign(x->n_ranks, nullptr);
     x->peer_flags.assign(x->n_ranks, nullptr);
+    x->peer_base.assign(x->n_ranks, nullptr);
     x->copy_stream.assign(x->n_ranks, nullptr);
     x->copy_done.assign(x->n_ranks, nullptr);
     for (uint32_t p = 0; p < x->n_ranks; p++) {
@@ -257,8 +268,8 @@ int tr_exchange_connect(tr_exchange *x, const void *blobs)
             x->peer_flags[p] = x->flags;
             continue;
         }
-        for (uint32_t s = 0; s < x->n_slots; s++)
-            HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_frame[s][p], b.frame[s], hipIpcMemLazyEnablePeerAccess));
+        HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_base[p], b.frames, hipIpcMemLazyEnablePeerAccess));
+        for (uint32_t s = 0; s < x->n_slots; s++) x->peer_frame[s][p] = x->peer_base[p] + (size_t)s * x->slot_stride;
         HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_flags[p], b.flags, hipIpcMemLazyEnablePeerAccess));
         HIP_TRY(hipStreamCreateWithFlags(&x->copy_stream[p], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&x->copy_done[p], hipEventDisableTiming));
@@ -285,6 +296,10 @@ int peer_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, 
 {
     const uint32_t g = x->generation[slot] + 1u;
     const uint32_t r = x->rank;
+    // dense, and everybody's range is known: pull (nothing but flags is written into a peer's memory)
+    const bool pull = !tiles && !x->range_bytes.empty();
+    if (pull && (offset != x->range_offset[r] || bytes != x->range_bytes[r]))
+        return tr::fail(TR_E_INVALID, "tr_exchange_all_gather: this rank's range differs from the one declared with tr_exchange_set_ranges");
     tr::DevFrame frame = {};
     if (tiles) {
         frame.width = tiles->width;
@@ -302,7 +317,11 @@ int peer_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, 
                 x->remote_clean[slot] = nullptr;
             }
             HIP_TRY(hipMalloc((void **)&x->remote_clean[slot], (size_t)x->n_ranks * (n_tiles ? n_tiles : 1u) * 4u));
-            HIP_TRY(hipMemsetAsync(x->remote_clean[slot], 0, (size_t)x->n_ranks * (n_tiles ? n_tiles : 1u) * 4u, stream));
+            // a slot that has never been exchanged holds zeros on every rank (tr_exchange_create fills the slots, and
+            // nobody but this rank writes its band of the peers' copies): the record starts as "zeros there"; after any
+            // exchange on the slot, with whatever grid, nothing is known
+            HIP_TRY(hipMemsetAsync(x->remote_clean[slot], x->generation[slot] == 0u ? 1 : 0,
+                                   (size_t)x->n_ranks * (n_tiles ? n_tiles : 1u) * 4u, stream));
             x->remote_tiles[slot] = n_tiles;
         }
         if (!x->d_tile_bytes) {
@@ -334,7 +353,13 @@ int peer_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, 
                                        x->remote_clean[slot] + (size_t)p * x->remote_tiles[slot], frame,
                                        x->flags + FlagIndex::error(), x->d_tile_bytes, c);
             if (rc) return tr::fail(TR_E_HIP, "tile push launch failed");
+        } else if (pull) {
+            // p's band out of p's slot into mine (flag "open" read as "p's band is ready", "arrived" as "I have pulled")
+            if (x->range_bytes[p])
+                HIP_TRY(hipMemcpyAsync(x->frame[slot] + x->range_offset[p], x->peer_frame[slot][p] + x->range_offset[p], x->range_bytes[p],
+                                       hipMemcpyDeviceToDevice, c));
         } else if (bytes) {
+            // (push: after a timed-out wait this copy still lands -- see the file comment; declare the ranges to pull)
             HIP_TRY(hipMemcpyAsync(x->peer_frame[slot][p] + offset, x->frame[slot] + offset, bytes, hipMemcpyDeviceToDevice, c));
         }
         // (after a timeout the peer is not told "arrived": tr_exchange_status reports TR_E_EXCHANGE on both sides)
@@ -353,10 +378,30 @@ int peer_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, 
     // (only now: a call that failed half way has not used up the generation its peers are waiting for -- the
     // exchange is unusable after such a failure, but the next call does not pretend to be a later generation)
     x->generation[slot] = g;
-    if (!tiles) x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);
+    if (!tiles) x->bytes_sent += (uint64_t)bytes * (x->n_ranks - 1u);  // (pulled or pushed: what leaves this rank per call)
     return TR_OK;
 }
 }  // namespace
+
+int tr_exchange_set_ranges(tr_exchange *x, const size_t *offsets, const size_t *bytes)
+{
+    if (!x) return tr::fail(TR_E_INVALID, "null exchange");
+    if (!offsets || !bytes) {  // back to the push form
+        x->range_offset.clear();
+        x->range_bytes.clear();
+        return TR_OK;
+    }
+    for (uint32_t p = 0; p < x->n_ranks; p++) {
+        if (offsets[p] > x->frame_bytes || bytes[p] > x->frame_bytes - offsets[p])
+            return tr::fail(TR_E_INVALID, "tr_exchange_set_ranges: a range lies outside the frame");
+        for (uint32_t q = 0; q < p; q++)
+            if (bytes[p] && bytes[q] && offsets[p] < offsets[q] + bytes[q] && offsets[q] < offsets[p] + bytes[p])
+                return tr::fail(TR_E_INVALID, "tr_exchange_set_ranges: the ranks' ranges overlap");
+    }
+    x->range_offset.assign(offsets, offsets + x->n_ranks);
+    x->range_bytes.assign(bytes, bytes + x->n_ranks);
+    return TR_OK;
+}
 
 int tr_exchange_all_gather(tr_exchange *x, uint32_t slot, size_t offset, size_t bytes, void *stream_)
 {
@@ -439,8 +484,7 @@ void tr_exchange_destroy(tr_exchange *x)
     if (x->comm) (void)g_rccl.CommDestroy(x->comm);
     for (uint32_t p = 0; p < x->peer_flags.size(); p++) {
         if (p == x->rank) continue;
-        for (uint32_t s = 0; s < x->n_slots; s++)
-            if (x->peer_frame[s].size() > p && x->peer_frame[s][p]) (void)hipIpcCloseMemHandle(x->peer_frame[s][p]);
+        if (x->peer_base.size() > p && x->peer_base[p]) (void)hipIpcCloseMemHandle(x->peer_base[p]);
         if (x->peer_flags[p]) (void)hipIpcCloseMemHandle(x->peer_flags[p]);
         if (x->copy_stream[p]) (void)hipStreamDestroy(x->copy_stream[p]);
         if (x->copy_done[p]) (void)hipEventDestroy(x->copy_done[p]);
@@ -451,8 +495,7 @@ void tr_exchange_destroy(tr_exchange *x)
     for (uint32_t k = 0; k < MAX_SLOTS; k++)
         if (x->remote_clean[k]) (void)hipFree(x->remote_clean[k]);
     if (x->d_tile_bytes) (void)hipFree(x->d_tile_bytes);
-    for (uint32_t s = 0; s < MAX_SLOTS; s++)
-        if (x->frame[s]) (void)hipFree(x->frame[s]);
+    if (x->frames) (void)hipFree(x->frames);
     if (x->flags) (void)hipFree(x->flags);
     delete x;
 }

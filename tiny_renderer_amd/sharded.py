@@ -69,29 +69,112 @@ def any_rank(flag, device=None):
     return worst_status(-1 if flag else 0, device) != 0
 
 
-class ShardedScene:
-    """Scene::new(...) for one rank of an initialised process group; every rank ends up with the whole frame."""
+class _DeviceBytes:
+    """A device buffer of the library's as something torch can wrap (CUDA array interface): the frame slots of a
+    PeerExchange become tensors, so that every frame -- whoever owns the memory -- is read the same way."""
 
-    def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=None, **scene_kw):
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class _TorchGather:
+    """exchange="torch": frame tensors of torch's, one in-place all_gather_into_tensor per frame (backend "nccl" = RCCL)."""
+    name = "torch"
+
+    def __init__(self, torch, dist, n_slots, frame_bytes, rank, world, device):
+        if dist.get_backend() != "nccl":
+            raise ValueError('exchange="torch" moves the bands with torch.distributed collectives on device tensors: the '
+                             'process group must use the "nccl" (RCCL) backend')
+        self._dist, self.rank = dist, rank
+        self.tensors = [torch.zeros(frame_bytes, dtype=torch.uint8, device="cuda:%d" % device) for _ in range(n_slots)]
+
+    def gather(self, slot, offset, nbytes, scene, stream):
+        t = self.tensors[slot]
+        self._dist.all_gather_into_tensor(t, t[offset:offset + nbytes])   # (on torch's current stream: the caller's `with`)
+
+    def bytes_sent(self):
+        return None
+
+    def status(self):
+        return 0
+
+    def close(self):
+        self.tensors = []
+
+
+class _LibraryGather:
+    """exchange="peer" / "peer-sparse" / "rccl": the library's own exchange (tr_exchange_*, PeerExchange below) owns the
+    frame slots; torch.distributed (any backend, gloo is enough) only carries the connection records."""
+
+    def __init__(self, torch, dist, n_slots, frame_bytes, rank, world, device, kind, ranges):
+        self.name = kind
+        self.sparse = kind == "peer-sparse"
+        self.x = PeerExchange(n_slots, frame_bytes, rank, world, device, backend="rccl" if kind == "rccl" else "peer")
+        self.x.set_ranges(*ranges)   # (dense peer exchange: pull -- nothing but flags is written into a peer's memory)
+        self.tensors = [torch.as_tensor(_DeviceBytes(self.x.frame_ptr(b), frame_bytes), device="cuda:%d" % device)
+                        for b in range(n_slots)]
+
+    def gather(self, slot, offset, nbytes, scene, stream):
+        if self.sparse:
+            self.x.all_gather_tiles(slot, scene.band_tiles(self.x.frame_ptr(slot)), stream.cuda_stream)
+        else:
+            self.x.all_gather(slot, offset, nbytes, stream.cuda_stream)
+
+    def bytes_sent(self):
+        return self.x.bytes_sent()
+
+    def status(self):
+        return self.x.status()
+
+    def close(self):
+        self.tensors = []
+        self.x.close()
+
+
+EXCHANGES = ("torch", "rccl", "peer", "peer-sparse")
+
+
+class ShardedScene:
+    """Scene::new(...) for one rank of an initialised process group; every rank ends up with the whole frame.
+
+    exchange: how the bands travel --
+      "torch"        torch.distributed's all_gather_into_tensor (RCCL; the default, north_star's collective),
+      "rccl"         the library's own RCCL communicator (tr_exchange_create_backend(TR_EXCHANGE_RCCL): no torch in the data path),
+      "peer"         the library's peer transport: bands pulled out of the peers' IPC-mapped slots by the DMA engines,
+      "peer-sparse"  ... tile by tile, tiles that are the cleared colour on both sides stay home (k_push_tiles).
+    The render side -- band scene, double-buffered frames, groups, overflow repair, statuses reduced over the ranks -- is
+    the same for all four.  RCCL wants one device per rank; the peer transports also run with several ranks on one GPU
+    (how the multi-rank path is rehearsed on a one-GPU box: tests/sharded_ranks_worker.py)."""
+
+    def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=None, exchange="torch", **scene_kw):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.width, self.height = int(width), int(height)
         self.band = band_rows(self.height, self.world, self.rank)
-        if len({band_rows(self.height, self.world, r)[1] - band_rows(self.height, self.world, r)[0]
-                for r in range(self.world)}) != 1:
+        bands = [band_rows(self.height, self.world, r) for r in range(self.world)]
+        if len({b[1] - b[0] for b in bands}) != 1:
             raise ValueError("frame height %d must divide by the number of GPUs %d (in-place all-gather)"
                              % (self.height, self.world))
+        if exchange not in EXCHANGES:
+            raise ValueError("exchange must be one of %s" % (EXCHANGES,))
         if device is None:
             device = torch.cuda.current_device()
+        self._device = device
         self._render = torch.cuda.Stream(device=device)
         self._comm = torch.cuda.Stream(device=device)
         assert self._render.cuda_stream != 0  # tr_options.stream = NULL would mean a library-owned stream
         n_all = self.width * self.height * 3
-        self._fbs = [torch.zeros(n_all, dtype=torch.uint8, device="cuda:%d" % device) for _ in range(2)]
-        n = (self.band[1] - self.band[0]) * self.width * 3
-        self._chunks = [fb[self.rank * n:(self.rank + 1) * n] for fb in self._fbs]
+        row = self.width * 3
+        self._band_bytes = (self.band[1] - self.band[0]) * row
+        self._band_offset = self.band[0] * row
+        # frame slots: 0, 1 = the per-frame protocol's double buffer; then two sets of `frames per launch` for render_frames
+        # (made when the first group is rendered: _group_slots)
+        self._exchange_kind = exchange
+        self._ranges = ([b[0] * row for b in bands], [(b[1] - b[0]) * row for b in bands])
+        self._gather = self._make_gather(2)
+        self._fbs = self._gather.tensors[:2]
         self._rendered = [torch.cuda.Event() for _ in range(2)]
         self._gathered = [torch.cuda.Event() for _ in range(2)]
         torch.cuda.synchronize(device)
@@ -106,6 +189,34 @@ class ShardedScene:
         self._last_was_cleared = True
         self._last_tensor = None   # where the newest frame is when it came from render_frames (else _fbs[_slot])
         self._last_group = None    # (frames, set) of the newest group: rendered again if its bins overflowed
+        self._timing = None        # enable_timing: [(render start, render end, gather start, gather end, frames)]
+
+    def enable_timing(self, on=True):
+        """Device times of this rank's renders and exchanges from now on (timing events on the two streams: a few
+        microseconds per frame or group, so only for a measuring leg); timings() reads them."""
+        self._timing = [] if on else None
+
+    def _stamp(self, stream):
+        e = self._torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
+    def timings(self):
+        """{"render_us", "gather_us"}: medians per FRAME over what was issued since enable_timing (waits for it)."""
+        import numpy as np
+        if not self._timing:
+            return {"render_us": None, "gather_us": None}
+        self._torch.cuda.synchronize()
+        r = [a.elapsed_time(b) * 1e3 / n for a, b, _, _, n in self._timing]
+        g = [c.elapsed_time(d) * 1e3 / n for _, _, c, d, n in self._timing]
+        return {"render_us": round(float(np.median(r)), 2), "gather_us": round(float(np.median(g)), 2)}
+
+    def _make_gather(self, n_slots):
+        torch, dist = self._torch, self._dist
+        n_all = self.width * self.height * 3
+        if self._exchange_kind == "torch":
+            return _TorchGather(torch, dist, n_slots, n_all, self.rank, self.world, self._device)
+        return _LibraryGather(torch, dist, n_slots, n_all, self.rank, self.world, self._device, self._exchange_kind, self._ranges)
 
     # --- the reference's methods -------------------------------------------------------------
     def clear(self):
@@ -130,12 +241,17 @@ class ShardedScene:
         with torch.cuda.stream(self._render):
             if self._used[b]:
                 self._render.wait_event(self._gathered[b])  # the slot's previous exchange has finished
+            t0 = self._stamp(self._render) if self._timing is not None else None
             self._scene.set_frame_buffer_device(self._fbs[b].data_ptr())
             self._scene.render()  # a caller's stream holds the frame's kernels when render() returns
+            t1 = self._stamp(self._render) if self._timing is not None else None
             self._rendered[b].record(self._render)
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(self._rendered[b])
-            dist.all_gather_into_tensor(self._fbs[b], self._chunks[b])
+            t2 = self._stamp(self._comm) if self._timing is not None else None
+            self._gather.gather(b, self._band_offset, self._band_bytes, self._scene, self._comm)
+            if self._timing is not None:
+                self._timing.append((t0, t1, t2, self._stamp(self._comm), 1))
             self._gathered[b].record(self._comm)
         self._used[b] = True
         self._last_was_cleared = self._cleared
@@ -157,14 +273,15 @@ class ShardedScene:
             return
         G = self._scene.frames_per_launch
         if not hasattr(self, "_gsets"):
-            n_all = self.width * self.height * 3
-            dev = self._fbs[0].device
-            self._gsets = [[torch.zeros(n_all, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(2)]
+            # two sets of G frame slots: an exchange of its own for them (the library's exchanges own their slots: up to 64)
+            if 2 * G > 64 and self._exchange_kind != "torch":
+                raise ValueError("frames_per_launch %d: the library's exchange holds 64 frame slots (two sets of 32)" % G)
+            self._ggather = self._make_gather(2 * G)
+            self._gsets = [self._ggather.tensors[:G], self._ggather.tensors[G:2 * G]]
             self._grendered = [torch.cuda.Event() for _ in range(2)]
             self._ggathered = [torch.cuda.Event() for _ in range(2)]
             self._gused = [False, False]
             self._gset = 1
-        n = (self.band[1] - self.band[0]) * self.width * 3
         for i0 in range(0, len(frames), G):
             g = min(G, len(frames) - i0)
             self._gset ^= 1
@@ -172,13 +289,17 @@ class ShardedScene:
             with torch.cuda.stream(self._render):
                 if self._gused[b]:
                     self._render.wait_event(self._ggathered[b])   # the set's previous exchange has finished
+                t0 = self._stamp(self._render) if self._timing is not None else None
                 self._scene.render_frames(frames[i0:i0 + g], [t.data_ptr() for t in self._gsets[b][:g]])
+                t1 = self._stamp(self._render) if self._timing is not None else None
                 self._grendered[b].record(self._render)
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(self._grendered[b])
+                t2 = self._stamp(self._comm) if self._timing is not None else None
                 for j in range(g):
-                    t = self._gsets[b][j]
-                    dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n])
+                    self._ggather.gather(b * G + j, self._band_offset, self._band_bytes, self._scene, self._comm)
+                if self._timing is not None:
+                    self._timing.append((t0, t1, t2, self._stamp(self._comm), g))
                 self._ggathered[b].record(self._comm)
             self._gused[b] = True
             self._last_group = (frames[i0:i0 + g].copy(), b)
@@ -201,6 +322,9 @@ class ShardedScene:
             message = ""
             try:
                 status = self._scene.sync()
+                for gth in (self._gather, getattr(self, "_ggather", None)):
+                    if gth is not None:
+                        gth.status()   # (a peer's band that did not arrive: TR_E_EXCHANGE)
             except TinyRendererError as e:
                 status, message = e.code, str(e)
             # every rank learns the most severe status of any rank and acts on THAT: a rank that raised on its own
@@ -241,9 +365,19 @@ class ShardedScene:
         """This rank's band scene (profiling, flush)."""
         return self._scene
 
+    def exchange_bytes_sent(self):
+        """Bytes this rank's exchanges have pushed / offered to its peers so far (None: torch's collective does not say)."""
+        n = [g.bytes_sent() for g in (self._gather, getattr(self, "_ggather", None)) if g is not None]
+        return None if any(v is None for v in n) else sum(n)
+
     def close(self):
         self._torch.cuda.synchronize()
         self._scene.close()
+        if self.world > 1:
+            self._dist.barrier()   # nobody unmaps a slot a peer may still be reading
+        for g in (self._gather, getattr(self, "_ggather", None)):
+            if g is not None:
+                g.close()
 
 
 
@@ -283,6 +417,14 @@ class PeerExchange:
 
     def all_gather(self, slot, offset, nbytes, hip_stream):
         self._check(self._L.tr_exchange_all_gather(self._h, slot, offset, nbytes, hip_stream))
+
+    def set_ranges(self, offsets, nbytes):
+        """tr_exchange_set_ranges: every rank's byte range of a frame (the dense peer exchange then pulls)."""
+        import ctypes as C
+        n = self.world
+        off = (C.c_size_t * n)(*[int(v) for v in offsets])
+        siz = (C.c_size_t * n)(*[int(v) for v in nbytes])
+        self._check(self._L.tr_exchange_set_ranges(self._h, off, siz))
 
     def all_gather_tiles(self, slot, tiles, hip_stream):
         """The sparse exchange (tr_exchange_all_gather_tiles): `tiles` = Scene.band_tiles(self.frame_ptr(slot)) of the
