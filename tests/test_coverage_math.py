@@ -187,3 +187,33 @@ def test_shadow_lookup_through_fast_clear_flags_equals_plain_lookup():
         ix = np.round(xs[2].astype(np.float32)).astype(np.uint64)
         idx = (ix + iy * np.uint64(W)) % np.uint64(2 ** 32)
         assert (idx < W * Hh).sum() > 100
+
+
+def test_darboux_third_column_only_matters_for_zero_sums():
+    """shader.rs:632-643 multiply the inverse of the local basis by vectors whose third component is 0.0, so each
+    component of local_x / local_y is (i0 * d1 + i1 * d2) + q * 0.0 with q = cofactor / det of the inverse's third column.
+    The two-pixel darboux closure leaves that column out (tr_shaders.h, fragment_color_pair).  Why that is exact:
+      * q is finite there (cofactors of unit rows over a determinant inside the guard [2^-40, 2^40]), so q * 0.0 is a
+        signed zero, and adding a zero of either sign to a NON-zero sum returns the sum, bit for bit;
+      * the only sums it can change are zeros: (-0) + (+0) = +0 -- and a zero component of local_x / local_y fails the
+        guard of the normalisation that consumes it (zero < 2^-40), which sends the pixel to the plain closure, where all
+        nine quotients are formed.
+    Enumerated here; the closures themselves are compared on whole models by tests/test_emulation.py and on the GPU."""
+    rng = np.random.default_rng(11)
+    # a non-zero sum plus a signed zero: unchanged, whatever the magnitudes and signs
+    s = np.concatenate([rng.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 200000).astype(np.float32),
+                        np.array([np.finfo(np.float32).tiny, -np.finfo(np.float32).tiny, 1e-45, -1e-45, 3.4e38, -3.4e38], np.float32)])
+    s = s[s != 0]
+    q = (rng.standard_normal(len(s)).astype(np.float32) * np.float32(2.0) ** rng.integers(-41, 41, len(s)).astype(np.float32))
+    term = q * np.float32(0.0)                       # +0 or -0 by the sign of q
+    assert set(np.unique(term.view(np.uint32))) <= {0, 0x80000000} and len(np.unique(term.view(np.uint32))) == 2
+    assert np.array_equal((s + term).view(np.uint32), s.view(np.uint32))
+    # the four zero cases: the sum's sign survives only with a term of the same sign -- these are the cases the guard
+    # hands to the plain closure (a zero operand of normalize3p: PAIR_GUARD_LO = 2^-40 > 0)
+    pz, nz = np.float32(0.0), np.float32(-0.0)
+    cases = {(a.tobytes(), b.tobytes()): (a + b) for a in (pz, nz) for b in (pz, nz)}
+    assert np.signbit(cases[(nz.tobytes(), nz.tobytes())]) and not np.signbit(cases[(nz.tobytes(), pz.tobytes())])
+    assert not np.signbit(cases[(pz.tobytes(), nz.tobytes())]) and not np.signbit(cases[(pz.tobytes(), pz.tobytes())])
+    assert np.float32(0.0) < np.float32(2.0) ** np.float32(-40)
+    # q finite: |cofactor| <= 2 (differences of products of unit-vector components), |det| >= 2^-40
+    assert np.isfinite(np.float32(2.0) / np.float32(2.0) ** np.float32(-40))

@@ -859,8 +859,14 @@ TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, con
         const vec3p local_z = mul_m3_v3p(make3p(vary(12), vary(13), vary(14)), make3p(vary(15), vary(16), vary(17)),
                                          make3p(vary(18), vary(19), vary(20)), bar);
         const vec3p r2 = normalize3p(local_z, g);
-        // 3x3 try_inverse of the matrix with rows r0, r1, r2 (nalgebra's cofactor form), nine quotients
-        // by one determinant
+        // 3x3 try_inverse of the matrix with rows r0, r1, r2 (nalgebra's cofactor form): SIX quotients by one
+        // determinant.  The inverse is only ever multiplied by (du1, du2, 0.0) and (dv1, dv2, 0.0)
+        // (shader.rs:632-643), so its third column enters as q * 0.0 added last: a signed zero (q = cofactor / det is
+        // finite here: the cofactors of that column are products of the unit rows r0, r1, the determinant is inside
+        // the guard), which changes the sum (a + b) only when that sum is itself a zero -- and a zero component of
+        // local_x / local_y puts the pixel outside the guard of the normalisation below, i.e. on the plain closure,
+        // which divides all nine.  The column's three cofactors, divisions and products are left out
+        // (tests/test_coverage_math.py::test_darboux_third_column_only_matters_for_zero_sums).
         const f2 m11 = vary(6), m12 = vary(7), m13 = vary(8);
         const f2 m21 = vary(9), m22 = vary(10), m23 = vary(11);
         const f2 m31 = r2.x, m32 = r2.y, m33 = r2.z;
@@ -870,19 +876,17 @@ TR_HD void fragment_color_pair(const DevUniforms &u, const DevTextures &tex, con
         const f2 det = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
         const f2 c10 = -minor_m11_m23;
         const f2 c01 = m13 * m32 - m33 * m12, c11 = m11 * m33 - m31 * m13, c21 = m12 * m31 - m32 * m11;
-        const f2 c02 = m12 * m23 - m22 * m13, c12 = m13 * m21 - m23 * m11, c22 = m11 * m22 - m21 * m12;
         guard_add(g, det);
         guard_add3(g, minor_m12_m23, c10, minor_m11_m22);
         guard_add3(g, c01, c11, c21);
-        guard_add3(g, c02, c12, c22);
         const f2 yd = rcp2(det);
         const vec3p i0 = make3p(div_by2_nonzero(minor_m12_m23, det, yd), div_by2_nonzero(c10, det, yd),
                                 div_by2_nonzero(minor_m11_m22, det, yd));
         const vec3p i1 = make3p(div_by2_nonzero(c01, det, yd), div_by2_nonzero(c11, det, yd), div_by2_nonzero(c21, det, yd));
-        const vec3p i2 = make3p(div_by2_nonzero(c02, det, yd), div_by2_nonzero(c12, det, yd), div_by2_nonzero(c22, det, yd));
-        const f2 u0 = vary(0), v0 = vary(1), zero = splat2(0.0f);
-        const vec3p local_x = mul_m3_v3p(i0, i1, i2, make3p(vary(2) - u0, vary(4) - u0, zero));
-        const vec3p local_y = mul_m3_v3p(i0, i1, i2, make3p(vary(3) - v0, vary(5) - v0, zero));
+        const f2 u0 = vary(0), v0 = vary(1);
+        const f2 du1 = vary(2) - u0, du2 = vary(4) - u0, dv1 = vary(3) - v0, dv2 = vary(5) - v0;
+        const vec3p local_x = make3p(i1.x * du2 + i0.x * du1, i1.y * du2 + i0.y * du1, i1.z * du2 + i0.z * du1);
+        const vec3p local_y = make3p(i1.x * dv2 + i0.x * dv1, i1.y * dv2 + i0.y * dv1, i1.z * dv2 + i0.z * dv1);
         // normalize(local_z) is r2 again (the reference recomputes it, shader.rs:644-648)
         const vec3p n = normalize3p(mul_m3_v3p(normalize3p(local_x, g), normalize3p(local_y, g), r2, nt), g);
         result = dot3p(tl, n);
