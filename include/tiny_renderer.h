@@ -81,6 +81,12 @@ typedef struct tr_image_rgb8 {
  * tr_scene_render_frames call to the next: whatever wrote it in between -- a post-process, a memset, an allocator
  * handing the address to another tensor -- a cleared render produces every pixel of its band. */
 #define TR_OPT_TRUST_FRAME_BUFFERS 0x8u
+/* Transient depth off.  By default the colour pass of a CLEARED frame resolves its depth on the chip and does not write
+ * it to the z buffer: nothing reads the z buffer of such a frame -- the next cleared frame overwrites it unseen -- and the
+ * first consumer that does want it (tr_scene_get_z_buffer / tr_scene_read_z_f32, or a tr_scene_render without a clear,
+ * which depth-tests against it: scene.rs:151) gets it from a repeat of the pass for the depth alone, so that what
+ * callers observe is unchanged.  With this flag every colour pass writes its depth, as the reference's does. */
+#define TR_OPT_STORE_DEPTH 0x10u
 
 typedef struct tr_options {
     uint32_t struct_size;      /* = sizeof(tr_options) */

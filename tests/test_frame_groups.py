@@ -504,3 +504,53 @@ def test_auto_groups_bin_overflow_and_teardown(synthetic):
     for q in p[:3]:
         _per_frame(gpu, q)
     gpu.close()   # three frames still on the host
+
+
+@pytest.mark.parametrize("pipe", ["phong", "shadow", "specular"])
+def test_transient_depth_is_made_real_on_demand(small_synthetic, pipe):
+    """The fused launches leave a cleared frame's depth on the chip (TileArgs::store); whoever wants the z buffer gets it
+    from a repeat of the colour pass for the depth alone: the z getters (bits and u8 view), a render WITHOUT a clear that
+    depth-tests against a kept frame (scene.rs:151), each kept frame in turn -- always the oracle's z, the colour
+    untouched, one repeat per frame (not per read) -- and TR_OPT_STORE_DEPTH switches the whole thing off."""
+    import tiny_renderer_amd as T
+    from oracle import oracle as O
+    mesh, texs = small_synthetic
+    W, Hh, n = 384, 256, 7
+    p = params(n)
+    expect = oracle_frames(W, Hh, mesh, texs, pipe, p)
+    exact = pipe in EXACT or specular_exact()
+    for store_depth in (False, True):
+        gpu = T.Scene(W, Hh, mesh, texs, pipe, frames_per_launch=4, store_depth=store_depth)
+        gpu.render_frames(p)
+        gpu.sync()
+        gpu.profile_enable(True)
+        for back in (2, 0, 1):                                    # kept frames, in no particular order
+            gpu.select_frame(back)
+            fo, zo, _ = expect[n - 1 - back]
+            assert np.array_equal(gpu.read_z_f32().view(np.uint32), zo), (pipe, store_depth, back)
+            assert np.array_equal(gpu.read_z_f32().view(np.uint32), zo)          # ... and again: already real
+            if exact:
+                assert np.array_equal(gpu.get_frame_buffer(), fo), "the depth-only repeat touched the colour"
+        launches = gpu.profile_read().get("k_tile", {"launches": 0})["launches"]
+        assert launches == (0 if store_depth else 3), (store_depth, launches)   # one repeat per frame, none when stored
+        gpu.profile_enable(False)
+        # the u8 view of the z buffer, straight after a group (nothing made real yet for the newest frame of a new call)
+        gpu.render_frames(p[:5])
+        cpu = O.Scene(W, Hh, mesh, texs, pipe)
+        q = p[4]
+        cpu.clear(), cpu.set_light_direction(q[0:3]), cpu.set_camera(q[3:6], q[6:9], q[9:12]), cpu.render()
+        assert np.array_equal(gpu.get_z_buffer(), cpu.get_z_buffer())
+        # an accumulating render on top of a kept frame whose depth was never stored
+        gpu.render_frames(p[:6])
+        gpu.select_frame(1)                                        # frame 4 again
+        for s in (gpu, cpu):
+            s.set_light_direction(H.light(0.9)), s.set_camera(*H.camera(2.2)), s.render()   # no clear
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32)), (pipe, store_depth, "accumulate")
+        if exact:
+            assert np.array_equal(gpu.get_frame_buffer(), cpu.get_frame_buffer())
+        # a clear after a deferred frame: the z buffer is the cleared value, nothing is repeated
+        gpu.render_frames(p[:3])
+        gpu.clear(), cpu.clear()
+        assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
+        cpu.close()
+        gpu.close()

@@ -28,6 +28,7 @@ TR_OPT_WINNER_TAP = 0x1
 TR_OPT_TILE_STAMPS = 0x2
 TR_OPT_NO_AUTO_GROUP = 0x4
 TR_OPT_TRUST_FRAME_BUFFERS = 0x8
+TR_OPT_STORE_DEPTH = 0x10
 
 
 class TinyRendererError(RuntimeError):

@@ -657,7 +657,7 @@ __device__ __forceinline__ uint32_t depth_order_bits(float z)
 // visited once per tile instead of once per column it touches.
 #define TR_TILE_KERNEL_ATTRS \
     __global__ __launch_bounds__(64 * TILE_WAVES) \
-        __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES, GROUP), tile_waves_per_eu(FS, TILE_WAVES, GROUP))))
+        __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES, MODE != 0), tile_waves_per_eu(FS, TILE_WAVES, MODE != 0))))
 
 // GROUP = false: one frame, arguments by value.
 // GROUP = true: a fused launch over a group of n_frames frames (tr_scene_render_frames): workgroup b renders
@@ -665,9 +665,14 @@ __device__ __forceinline__ uint32_t depth_order_bits(float z)
 // table in device memory -- so the heavy tiles of ALL the frames come first and the light and empty ones
 // fill the slots they free: one frame's drain (a third of a lone 4096^2 launch runs on a machine that is
 // emptying, and a small frame never fills it at all) is the next frame's start.
-template <int FS, int TILE_WAVES, bool SHARED, bool GROUP>
+// MODE 0: one frame, arguments by value; what the pass writes is TileArgs::store, looked up at run time (the depth-only
+// repeat of a colour pass is such a launch).  MODE 1 / 2: a fused launch; 2 = transient depth, decided at COMPILE time --
+// a run-time flag skipped the stores but kept the arithmetic behind them (the survivors' z, the depth addresses), and
+// with it the gain (same box: 28.5 -> 28.3 us per frame against 27.4 for the compiled-out form).
+template <int FS, int TILE_WAVES, bool SHARED, int MODE>
 TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ table, uint32_t n_frames)
 {
+    constexpr bool GROUP = MODE != 0;
     static_assert(TILE_WAVES == 4 || TILE_WAVES == 8 || TILE_WAVES == 16, "a wave covers a 32, 16 or 8 pixel wide column of the tile");
     constexpr int TILE_THREADS = 64 * TILE_WAVES;
     constexpr int QUAD_COLUMN = TILE_W / TILE_WAVES;  // width of a wave's column when columns are owned
@@ -702,6 +707,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const uint32_t frame_of_group = blockIdx.x % n_fr;
     // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
     const TileArgs &a = GROUP ? *(const TileArgs *)((constant_ptr<TileArgs>)table + frame_of_group) : args;
+    const bool st_z = FS == FS_DEPTH || (MODE == 0 ? (a.store & TR_STORE_DEPTH) != 0u : MODE == 1);
+    const bool st_c = FS == FS_DEPTH || MODE != 0 || (a.store & TR_STORE_COLOR) != 0u;
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     uint32_t entry = blockIdx.x / n_fr;
     uint32_t list = 0u;
@@ -729,8 +736,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
             // already holds them (it was empty the last time it was written, too: most of a frame,
             // most of the time); its z stays unwritten behind the tile's fast-clear flag (depth passes
-            // write their f32::MIN)
-            const bool stale = DEPTH || a.fbclean == nullptr || a.fbclean[tile] == 0u;
+            // write their f32::MIN).  (A pass that leaves the colour or the depth out -- TileArgs::store -- leaves the
+            // respective memory and flags of the tile alone.)
+            const bool stale = st_c && (DEPTH || a.fbclean == nullptr || a.fbclean[tile] == 0u);
             // every wave has read the flag before the first one raises it (a wave that came late would find
             // it up and leave its share of the tile unwritten)
             __syncthreads();
@@ -739,7 +747,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                                           (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
                 if (!DEPTH && tid == 0u && a.fbclean) a.fbclean[tile] = 1u;
             }
-            if (tid == 0u && a.zclean) a.zclean[tile] = 1u;
+            if (tid == 0u && a.zclean && st_z) a.zclean[tile] = 1u;
         }
         return;
     }
@@ -1171,7 +1179,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                             mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
                             mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
         uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
-        if (!DEPTH) {
+        if (!DEPTH && st_c) {   // (a depth-only repeat of a colour pass: the z, no closure)
             // uv = vertex_uvs * bar (2x3 gemv), both pixels
             f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
             f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
@@ -1271,7 +1279,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     auto store_pixel = [&](int32_t row, int32_t py_, bool live, bool won, float zv, uint32_t rgbv, uint32_t triv, bool with_winner) {
         const uint32_t zoff = mul24((uint32_t)row, Wu) + (uint32_t)hx;
         const uint32_t coff = mul24((uint32_t)(STRIP_ROWS - 1 - row), W3);  // the row's first byte
-        if (!DEPTH && !a.fresh && live && !won) {
+        if (!DEPTH && !a.fresh && live && !won && st_c) {
             // untouched pixel of an accumulate render: its colour may share a dword with a
             // touched neighbour, so fetch it
             const uint8_t *old = fb_strip + (coff + 3u * (uint32_t)hx);
@@ -1279,8 +1287,10 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         }
         // depth: only pixels that changed (or every live pixel of a fresh tile)
         const bool put = live && (won || zfresh);
-        if (put) depth_strip[zoff] = zv;
-        if (!DEPTH) {
+        // (TileArgs::store: a cleared frame's colour pass may leave its depth on the chip -- nothing reads the z buffer
+        // of such a frame unless a getter or an accumulating render asks, and then the pass is repeated for the depth alone)
+        if (put && st_z) depth_strip[zoff] = zv;
+        if (!DEPTH && st_c) {
             if (winner_strip && put && with_winner) winner_strip[zoff] = triv;
             if (a.aligned4) {
                 // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
@@ -1351,8 +1361,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             shade_steps(std::false_type{}, std::false_type{}, redo);
     }
 
-    if (a.zclean && tid == 0u) a.zclean[tile] = 0u;
-    if (!DEPTH && a.fbclean && tid == 0u) a.fbclean[tile] = 0u;
+    if (a.zclean && tid == 0u && st_z) a.zclean[tile] = 0u;
+    if (!DEPTH && a.fbclean && tid == 0u && st_c) a.fbclean[tile] = 0u;
 
     if (stamps) {
         __syncthreads();
@@ -1750,12 +1760,16 @@ static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const 
                              hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
     const dim3 grid(n_tiles * (group ? n_frames : 1u)), block(64 * WAVES);
+    // (a fused launch whose frames leave their depth on the chip: `a` -- what the group's frames have in common -- says so)
+    const bool transient = group && fs != FS_DEPTH && a.store == TR_STORE_COLOR;
 #define TR_TILE_CASE(F)                                                                                                  \
     case F:                                                                                                              \
-        if (group)                                                                                                       \
-            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, true>), grid, block, 0, st, start, done, 0, a, group, n_frames); \
+        if (transient)                                                                                                   \
+            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, (F == FS_DEPTH ? 1 : 2)>), grid, block, 0, st, start, done, 0, a, group, n_frames); \
+        else if (group)                                                                                                  \
+            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, 1>), grid, block, 0, st, start, done, 0, a, group, n_frames); \
         else                                                                                                             \
-            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, false>), grid, block, 0, st, start, done, 0, a, nullptr, 0u); \
+            hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, 0>), grid, block, 0, st, start, done, 0, a, nullptr, 0u); \
         break;
     switch (fs) {
     TR_TILE_CASE(FS_DEFAULT)

@@ -239,11 +239,17 @@ struct tr_scene {
         float *shadow = nullptr;
         uint32_t *sclean = nullptr;
         uint8_t *fb = nullptr;
+        // Transient depth: the slot's frame was rendered from cleared targets with its depth left on the chip
+        // (TileArgs::store): z memory and fast-clear flags say nothing; the frame's z is what `z_params` renders.
+        // ensure_depth() repeats the colour pass for the depth alone when somebody wants the z buffer.
+        bool z_deferred = false;
+        tr_frame_params z_params = {};
     };
     std::vector<FrameSlot> slots;
     int cur_slot = 0;
     uint32_t frames_per_launch = 0;  // tr_options.frames_per_launch; 0 = by tile count
     uint32_t max_slots = 0;          // tr_options.max_frame_slots; 0 = automatic
+    bool transient_depth = true;     // a cleared frame's colour pass leaves its depth on the chip (TR_OPT_STORE_DEPTH / TR_DEFER_Z=0: off)
     bool no_long_runs = false;       // the large groups' resources did not fit the device once: the usual groups from then on
     bool broken = false;             // a tile kernel could not be launched behind its chain: counters and ranges are stale
     // One group in flight: bins, counters, work lists and argument tables of its frames' passes
@@ -610,6 +616,7 @@ int flush_clear_color(tr_scene *s)
     Timed t(s, K_CLEAR);
     // z: raise every tile's fast-clear flag; colour (and the winner tap) are real memory
     HIP_TRY(hipMemsetAsync(s->d_zclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
+    s->slots[(size_t)s->cur_slot].z_deferred = false;   // (the slot's z IS the cleared value now)
     HIP_TRY(hipMemsetAsync(s->d_fb + fb_first, 0, n * 3, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_fbclean, 0xFF, (size_t)s->n_tiles * 4, s->stream));
     if (s->d_winner) HIP_TRY(hipMemsetAsync(s->d_winner + z_first, 0xFF, n * 4, s->stream));
@@ -658,6 +665,7 @@ int materialize_depth(tr_scene *s)
 
 int render_frame(tr_scene *s);
 int replay_tail(tr_scene *s);
+int ensure_depth(tr_scene *s);
 
 // Tiles the bins must cover: a band scene's colour passes touch its own rows only; the depth passes of
 // shadow / occlusion fill the whole shadow buffer on every rank (shader.rs:774-778).
@@ -874,7 +882,17 @@ void tile_layout(const tr_scene *s, uint64_t tiles_in_launch, uint32_t tiles_per
     if (s->mesh.n_tri > (1u << 20)) shared = 0;  // (a TILE with more records than the slot field holds resolves by columns: k_tile)
 }
 
-int run_pass(tr_scene *s, const PassDesc &p)
+// May a cleared frame's colour pass leave its depth on the chip?  Not with the winner tap or the tile stamps (single
+// diagnostic buffers whose tests read the z buffer after every frame: nothing to gain).
+bool defer_depth(const tr_scene *s)
+{
+    static const int env_on = getenv("TR_DEFER_Z") ? atoi(getenv("TR_DEFER_Z")) : 1;
+    return env_on && s->transient_depth && !s->d_winner && !s->d_stamps;
+}
+
+// depth_only: the repeat of a colour pass for its depth alone (ensure_depth): from cleared targets, nothing of the
+// scene's clear / colour state is consumed or changed.
+int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
 {
     DevUniforms du;
     int st = pass_uniforms(s, p, du);
@@ -891,6 +909,8 @@ int run_pass(tr_scene *s, const PassDesc &p)
     if (depth_pass) {
         fresh = s->shadow_cleared ? 1u : 0u;
         s->shadow_cleared = false;
+    } else if (depth_only) {
+        fresh = 1u;
     } else {
         fresh = s->z_fb_cleared ? 1u : 0u;
         s->z_fb_cleared = false;
@@ -945,10 +965,25 @@ int run_pass(tr_scene *s, const PassDesc &p)
     ta.err = s->d_err;
     ta.alarm = s->d_alarm;
     ta.fresh = fresh;
+    ta.store = TR_STORE_DEPTH | TR_STORE_COLOR;
+    if (!depth_pass) {
+        tr_scene::FrameSlot &slot = s->slots[(size_t)s->cur_slot];
+        if (depth_only) {
+            ta.store = TR_STORE_DEPTH;
+            ta.winner = nullptr;
+            ta.stamps = nullptr;
+            slot.z_deferred = false;
+        } else {
+            // (a per-frame launch writes its depth: only the fused launches of frame groups leave it on the chip --
+            // decided at compile time there, k_tile's MODE -- and an accumulating render has had the slot's depth made
+            // real before it came here: ensure_depth, tr_scene_render)
+            slot.z_deferred = false;
+        }
+    }
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
-    ta.stamps = depth_pass ? nullptr : s->d_stamps;
-    const bool lit_pass = tile_fs(s, p.fs) == (int)FS_LIT;
+    if (!depth_only) ta.stamps = depth_pass ? nullptr : s->d_stamps;
+    const bool lit_pass = !depth_only && tile_fs(s, p.fs) == (int)FS_LIT;
     if (lit_pass) lit_args(s, s->d_lit[p_seq % LOOKAHEAD], sa, ta);
     // setup on its own stream: after the tile kernel of pass p - LOOKAHEAD, before the tile kernel of pass p.
     // With NOTHING in flight (a frame rendered and read, rendered and read: the interactive loop) the chain has
@@ -994,7 +1029,7 @@ int run_pass(tr_scene *s, const PassDesc &p)
         }
         HIP_TRY(hipEventRecord(s->ev_setup[p_seq % RING], chain));
     }
-    pt.fs = tile_fs(s, p.fs);
+    pt.fs = depth_only ? p.fs : tile_fs(s, p.fs);
     pt.kernel_id = depth_pass ? K_TILE_DEPTH : K_TILE;
     pt.p_seq = p_seq;
     pt.args = ta;
@@ -1042,6 +1077,31 @@ int render_frame(tr_scene *s)
         }
     }
     return TR_OK;
+}
+
+// Makes the current slot's z buffer real.  A cleared frame's colour pass leaves its depth on the chip (transient depth:
+// nothing reads the z buffer of such a frame -- the next cleared frame overwrites it unseen); the first consumer that
+// does want it -- tr_scene_read_z_f32 / tr_scene_get_z_buffer, a render WITHOUT a clear, which depth-tests against it
+// (scene.rs:151) -- repeats the frame's colour pass for the depth alone: same light and camera, same cull and
+// projection, same resolve; colour, winner words, flags of the frame buffer and the scene's clear state untouched.
+int ensure_depth(tr_scene *s)
+{
+    tr_scene::FrameSlot &slot = s->slots[(size_t)s->cur_slot];
+    if (!slot.z_deferred) return TR_OK;
+    int st = submit_pending(s);   // (the frame itself, should it still be held back)
+    if (st != TR_OK) return st;
+    if (!slot.z_deferred) return TR_OK;
+    float keep[12];
+    memcpy(keep, s->light, 12); memcpy(keep + 3, s->from, 12); memcpy(keep + 6, s->at, 12); memcpy(keep + 9, s->up, 12);
+    const tr_frame_params &q = slot.z_params;
+    memcpy(s->light, q.light, 12); memcpy(s->from, q.look_from, 12); memcpy(s->at, q.look_at, 12); memcpy(s->up, q.up, 12);
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    const int host_status = s->host_status;
+    st = run_pass(s, pd.pass[pd.n_passes - 1], true);
+    if (st == TR_OK) st = submit_pending_tiles(s);
+    s->host_status = host_status;
+    memcpy(s->light, keep, 12); memcpy(s->from, keep + 3, 12); memcpy(s->at, keep + 6, 12); memcpy(s->up, keep + 9, 12);
+    return st;
 }
 
 
@@ -1267,7 +1327,9 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
     for (uint32_t j = 0; j < g && st == TR_OK; j++) {
         memcpy(s->light, p[j].light, 12); memcpy(s->from, p[j].look_from, 12);
         memcpy(s->at, p[j].look_at, 12); memcpy(s->up, p[j].up, 12);
-        const tr_scene::FrameSlot &slot = s->slots[(size_t)slot_of[j]];
+        tr_scene::FrameSlot &slot = s->slots[(size_t)slot_of[j]];
+        slot.z_deferred = defer_depth(s);   // (what the slot's z is then: this frame)
+        slot.z_params = p[j];
         uint8_t *fb = fbs ? (uint8_t *)fbs[j] : nullptr;
         const bool callers = fb != nullptr;
         if (!fb) st = slot_own_fb(s, slot_of[j], &fb);
@@ -1315,6 +1377,7 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             ta.err = s->d_err;
             ta.alarm = s->d_alarm;
             ta.fresh = 1u;  // every frame of a group starts from cleared targets
+            ta.store = (!depth_pass && defer_depth(s)) ? TR_STORE_COLOR : (TR_STORE_DEPTH | TR_STORE_COLOR);
             ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
             ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
             ta.stamps = depth_pass ? nullptr : s->d_stamps;
@@ -1791,6 +1854,7 @@ int create(uint32_t width, uint32_t height, const tr_mesh *mesh, const tr_image_
         return tr::fail(TR_E_INVALID, "frames_per_launch exceeds max_frame_slots (every frame of a launch needs a slot)");
     s->max_slots = o.max_frame_slots;
     s->auto_group = (o.flags & TR_OPT_NO_AUTO_GROUP) == 0;
+    s->transient_depth = (o.flags & TR_OPT_STORE_DEPTH) == 0;
 
     if (o.stream) {
         s->stream = (hipStream_t)o.stream;
@@ -2188,6 +2252,8 @@ int tr_scene_render(tr_scene *s)
         // frames held back before it go first (it may render onto the last of them)
         int st = flush_deferred(s, false);
         if (st != TR_OK) return st;
+        // a render without a clear depth-tests against the frame so far: its depth must be in memory
+        if (!s->z_fb_cleared && (st = ensure_depth(s)) != TR_OK) return st;
         return render_frame(s);
     }
     // a cleared frame on the library's own stream: recorded now, rendered with its neighbours ("Automatic frame
@@ -2458,7 +2524,8 @@ int tr_scene_get_z_buffer(tr_scene *s, uint8_t *rgb)
     if (!s || !rgb) return tr::fail(TR_E_INVALID, "null argument");
     int fst = sync_and_status(s);
     if (fatal(fst)) return fst;
-    int st = flush_clear_color(s);
+    int st = s->z_fb_cleared ? TR_OK : ensure_depth(s);
+    if (st == TR_OK) st = flush_clear_color(s);
     if (st == TR_OK) st = materialize_depth(s);
     if (st != TR_OK) return st;
     return depth_view(s, fst, s->d_z, rgb);
@@ -2480,7 +2547,8 @@ int tr_scene_read_z_f32(tr_scene *s, float *out)
     if (!s || !out) return tr::fail(TR_E_INVALID, "null argument");
     int fst = sync_and_status(s);
     if (fatal(fst)) return fst;
-    int st = flush_clear_color(s);
+    int st = s->z_fb_cleared ? TR_OK : ensure_depth(s);
+    if (st == TR_OK) st = flush_clear_color(s);
     if (st == TR_OK) st = materialize_depth(s);
     if (st != TR_OK) return st;
     return finish_read_back(s, fst, out, s->d_z, (size_t)s->width * s->height * 4);

@@ -171,6 +171,8 @@ struct alignas(16) WorkItem {
     uint32_t pad;
 };
 
+constexpr uint32_t TR_STORE_DEPTH = 1u, TR_STORE_COLOR = 2u;
+
 struct SetupArgs {
     DevMesh mesh;
     DevFrame frame;
@@ -224,6 +226,11 @@ struct TileArgs {
     // no device-to-host copy at its sync (10 us of the 13 an empty tr_scene_sync took).
     uint32_t *alarm;
     uint32_t fresh;     // 1: target buffers are logically cleared (scene.rs:128-137 folded in)
+    // What a COLOUR pass writes to memory (TR_STORE_*; depth passes always write their shadow buffer).  Both: the
+    // reference's pass.  Colour only: "transient depth" -- the z of a cleared frame is resolved in LDS and left there,
+    // as a tile-based GPU leaves a depth attachment nobody loads on the chip; should a getter or an accumulating
+    // render want the z buffer after all, the same pass is repeated with depth only (tr_scene.cpp, ensure_depth).
+    uint32_t store;
     uint32_t aligned16; // 1: width % 16 == 0, cleared rows can be written in 16-byte pieces
     uint32_t aligned4;  // 1: width % 4 == 0, colour rows can be written as packed dwords
     uint64_t *stamps;   // diagnostic only (TR_OPT_TILE_STAMPS): per tile {start, end, polygons, hw id}; else nullptr

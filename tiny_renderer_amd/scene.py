@@ -39,7 +39,7 @@ class Scene:
     def __init__(self, width, height, mesh, textures, shader_pipeline_name, *, device=-1,
                  winner_tap=False, tile_stamps=False, band_rows=None, stream=None, frame_buffer_device=None,
                  bin_capacity=0, tile_waves=0, tile_mode=0, frames_per_launch=0, auto_group=True,
-                 trust_frame_buffers=False, max_frame_slots=0):
+                 trust_frame_buffers=False, max_frame_slots=0, store_depth=False):
         L = load_library()
         self.width, self.height = int(width), int(height)
         keep = []
@@ -56,7 +56,8 @@ class Scene:
         o.device = device
         o.flags = ((_lib.TR_OPT_WINNER_TAP if winner_tap else 0) | (_lib.TR_OPT_TILE_STAMPS if tile_stamps else 0)
                    | (0 if auto_group else _lib.TR_OPT_NO_AUTO_GROUP)
-                   | (_lib.TR_OPT_TRUST_FRAME_BUFFERS if trust_frame_buffers else 0))
+                   | (_lib.TR_OPT_TRUST_FRAME_BUFFERS if trust_frame_buffers else 0)
+                   | (_lib.TR_OPT_STORE_DEPTH if store_depth else 0))
         if band_rows is not None:
             o.band_row0, o.band_row1 = int(band_rows[0]), int(band_rows[1])
         o.stream = stream
