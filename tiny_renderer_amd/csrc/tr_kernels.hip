@@ -529,7 +529,7 @@ __device__ __forceinline__ uint32_t shared_key_slot(uint32_t tx, uint32_t qy)
 
 // Streams the cleared value of a tile (scene.rs:128-137 folded into the render): z / shadow =
 // f32::MIN, rgb = 0.  Whole-tile rows are whole cache lines; 16 B per lane when width % 16 == 0.
-template <bool DEPTH, int TILE_THREADS>
+template <bool DEPTH, int TILE_THREADS, bool WINNER>
 __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t tile_x0, int32_t tile_y0,
                                                    bool with_depth)
 {
@@ -553,7 +553,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
                 if (xb < W * 3 && y >= a.frame.band_y0 && y < a.frame.band_y1)
                     *reinterpret_cast<uint4 *>(a.fb + (size_t)(H - 1 - y) * W * 3 + xb) = zero;
             }
-            if (a.winner) {
+            if (WINNER && a.winner) {
                 const uint4 none = make_uint4(NO_WINNER, NO_WINNER, NO_WINNER, NO_WINNER);
                 for (uint32_t c = tid; c < (uint32_t)TILE_H * 32u; c += (uint32_t)TILE_THREADS) {
                     const int32_t y = tile_y0 + (int32_t)(c >> 5), x = tile_x0 + (int32_t)(c & 31u) * 4;
@@ -572,7 +572,7 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
                     px[0] = 0;
                     px[1] = 0;
                     px[2] = 0;
-                    if (a.winner) a.winner[(size_t)y * W + x] = NO_WINNER;
+                    if (WINNER && a.winner) a.winner[(size_t)y * W + x] = NO_WINNER;
                 }
             }
         }
@@ -707,6 +707,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const uint32_t frame_of_group = blockIdx.x % n_fr;
     // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
     const TileArgs &a = GROUP ? *(const TileArgs *)((constant_ptr<TileArgs>)table + frame_of_group) : args;
+    // (every frame of a fused launch starts from cleared targets and has no winner tap -- run_group, tr_scene.cpp: known
+    // when the kernel is compiled, so the accumulate paths and the tap's stores are not even there)
+    const bool fresh = GROUP || a.fresh != 0u;
     const bool st_z = FS == FS_DEPTH || (MODE == 0 ? (a.store & TR_STORE_DEPTH) != 0u : MODE == 1);
     const bool st_c = FS == FS_DEPTH || MODE != 0 || (a.store & TR_STORE_COLOR) != 0u;
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
@@ -732,7 +735,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     // (k_bin has counted the tile's counter down to the start of its range; the set's next pass counts from zero)
     if (tid == 0u && list != (uint32_t)ORDER_EMPTY) a.tile_count[tile] = 0u;
     if (n == 0u) {
-        if (a.fresh) {
+        if (fresh) {
             // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
             // already holds them (it was empty the last time it was written, too: most of a frame,
             // most of the time); its z stays unwritten behind the tile's fast-clear flag (depth passes
@@ -743,7 +746,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             // it up and leave its share of the tile unwritten)
             __syncthreads();
             if (stale) {
-                write_cleared_tile<DEPTH, TILE_THREADS>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
+                write_cleared_tile<DEPTH, TILE_THREADS, !GROUP>(a, (int32_t)(tile % a.frame.ntx) * TILE_W,
                                           (a.frame.ty_base + (int32_t)(tile / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
                 if (!DEPTH && tid == 0u && a.fbclean) a.fbclean[tile] = 1u;
             }
@@ -766,7 +769,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     float *depth = DEPTH ? a.shadow : a.zbuf;
     // is every z of this tile logically f32::MIN (cleared frame, or fast-clear flag still set)?
     // then nothing is read and every live z is written, after which the flag is down
-    const bool zfresh = a.fresh || (a.zclean && a.zclean[tile] != 0u);
+    const bool zfresh = fresh || (a.zclean && a.zclean[tile] != 0u);
     const int32_t qy0 = tile_y0;
     constexpr uint32_t PREV_TAG = DEPTH ? 0u : 0xFFFFFFFFu;  // shared mode: tie-break word of the buffer's old content
     // A launch compiled for the shared resolve still gives tiles with few polygons to the column form:
@@ -1122,7 +1125,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     // the flipped image), so every lane offset is non-negative.  Rows outside the frame or the
     // band give addresses that are formed but never used.
     float *const depth_strip = depth + ((int64_t)sy0 * W + sx0);
-    uint32_t *const winner_strip = a.winner ? a.winner + ((int64_t)sy0 * W + sx0) : nullptr;
+    uint32_t *const winner_strip = (!GROUP && a.winner) ? a.winner + ((int64_t)sy0 * W + sx0) : nullptr;
     uint8_t *const fb_strip = DEPTH ? nullptr : a.fb + ((int64_t)(H - sy0 - STRIP_ROWS) * W + sx0) * 3;
     const uint32_t Wu = (uint32_t)W, W3 = 3u * (uint32_t)W;
     const bool col_live = px < W;
@@ -1279,7 +1282,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     auto store_pixel = [&](int32_t row, int32_t py_, bool live, bool won, float zv, uint32_t rgbv, uint32_t triv, bool with_winner) {
         const uint32_t zoff = mul24((uint32_t)row, Wu) + (uint32_t)hx;
         const uint32_t coff = mul24((uint32_t)(STRIP_ROWS - 1 - row), W3);  // the row's first byte
-        if (!DEPTH && !a.fresh && live && !won && st_c) {
+        if (!DEPTH && !fresh && live && !won && st_c) {
             // untouched pixel of an accumulate render: its colour may share a dword with a
             // touched neighbour, so fetch it
             const uint8_t *old = fb_strip + (coff + 3u * (uint32_t)hx);
