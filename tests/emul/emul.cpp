@@ -449,3 +449,69 @@ extern "C" void tr_emul_pair_counts(uint64_t out[2])
     out[0] = g_pair_fast;
     out[1] = g_pair_plain;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The host's planner (tiny_renderer_amd/csrc/tr_plan.h: the decisions of tr_scene.cpp, free of HIP), bound for
+// tests/test_planner.py.
+// ---------------------------------------------------------------------------------------------------------------------
+#include "tr_plan.h"
+
+extern "C" {
+
+// shape: n_tiles, frames_per_launch, max_slots, forced, winner_tap, tile_stamps, no_long_runs, n_passes, then two u64:
+// pool_bytes_per_pass, pixels.  out: group_size, long_run_group_size
+void tr_emul_plan_sizes(const uint32_t *shape, const uint64_t *big, uint32_t *out)
+{
+    tr::plan::SceneShape s;
+    s.n_tiles = shape[0]; s.frames_per_launch = shape[1]; s.max_slots = shape[2]; s.forced = shape[3];
+    s.winner_tap = shape[4] != 0; s.tile_stamps = shape[5] != 0; s.no_long_runs = shape[6] != 0; s.n_passes = shape[7];
+    s.pool_bytes_per_pass = big[0]; s.pixels = big[1];
+    out[0] = tr::plan::group_size(s);
+    out[1] = tr::plan::long_run_group_size(s);
+}
+
+// returns the number of groups; sizes[] (cap entries), info = {slots, set_frames, kept}
+uint32_t tr_emul_plan_call(uint32_t n, uint32_t G, uint32_t long_run, int automatic, uint32_t growth, uint32_t short_factor,
+                           uint32_t *sizes, uint32_t cap, uint32_t *info)
+{
+    const tr::plan::CallPlan p = tr::plan::plan_call(n, G, long_run, automatic != 0, growth, short_factor);
+    for (size_t k = 0; k < p.sizes.size() && k < cap; k++) sizes[k] = p.sizes[k];
+    info[0] = p.slots; info[1] = p.set_frames; info[2] = p.kept;
+    return (uint32_t)p.sizes.size();
+}
+
+// fbs: g buffer ids (0 = the current slot's own buffer, 1..15 = other buffers of the scene's, >= 16 = callers' buffers);
+// out: per frame {slot, fb id or 0xFFFFFFFF for "the slot's own", unreplayable}
+void tr_emul_plan_deferred(const uint32_t *fbs, uint32_t g, int cur_slot, uint32_t *out)
+{
+    std::vector<const void *> wanted(g);
+    for (uint32_t j = 0; j < g; j++) wanted[j] = (const void *)(uintptr_t)(fbs[j] + 1u);
+    const std::vector<tr::plan::DeferredTarget> t = tr::plan::plan_deferred(
+        wanted, cur_slot, (const void *)(uintptr_t)1u, [](const void *fb) { return (uintptr_t)fb <= 16u; });
+    for (uint32_t j = 0; j < g; j++) {
+        out[3 * j + 0] = (uint32_t)t[j].slot;
+        out[3 * j + 1] = t[j].fb ? (uint32_t)((uintptr_t)t[j].fb - 1u) : 0xFFFFFFFFu;
+        out[3 * j + 2] = t[j].unreplayable ? 1u : 0u;
+    }
+}
+
+int tr_emul_plan_overflow(uint64_t first_bad, uint64_t observed, uint64_t unreplayable, int last_was_group, int last_valid,
+                          int last_started_cleared)
+{
+    tr::plan::OverflowState o = { first_bad, observed, unreplayable, last_was_group != 0, last_valid != 0, last_started_cleared != 0 };
+    return (int)tr::plan::overflow_action(o);
+}
+
+uint64_t tr_emul_plan_grown_pool(uint64_t cap, uint64_t need) { return tr::plan::grown_pool(cap, need); }
+
+int tr_emul_plan_handover(uint32_t pending, int nothing_submitted, int newest_tile_done)
+{
+    return (int)tr::plan::handover(pending, nothing_submitted != 0, newest_tile_done != 0);
+}
+
+void tr_emul_plan_constants(int *out)
+{
+    out[0] = tr::plan::GROUP_MAX; out[1] = tr::plan::GROUP_SETS; out[2] = tr::plan::LOOKAHEAD; out[3] = tr::plan::BATCH;
+}
+
+}  // extern "C"

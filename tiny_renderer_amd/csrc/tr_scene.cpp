@@ -22,6 +22,7 @@
 #include "tr_error.h"
 #include "tr_kernels.h"
 #include "tr_math.h"
+#include "tr_plan.h"
 #include "tr_powf.h"
 #include "tr_prepare.h"
 #include "tr_shaders.h"
@@ -108,7 +109,7 @@ struct EventPair {
 // the critical path of the frame loop; 3 gave it two (44.1 -> 42.4 us per frame); 5 lets four passes
 // wait on the host for their setups to finish, so that their tile kernels need no wait packet (below).
 // Costs LOOKAHEAD sets of bins (0.2 GB each at 4096^2) -- cheap next to 288 GB.
-constexpr int LOOKAHEAD = 5;
+using tr::plan::LOOKAHEAD;   // (tr_plan.h: the decisions of this file live there, testable without a GPU)
 constexpr uint64_t LIT_PIXELS_PER_TEXEL = 16;  // frame pixels per image texel from which the lit path (k_lit) is taken
 constexpr int SETS = LOOKAHEAD + 1;
 // Handing tile kernels to the main stream.  The tile kernel of pass p must run after that pass's setup
@@ -130,7 +131,7 @@ constexpr int SETS = LOOKAHEAD + 1;
 // have been submitted by then.  Nothing observable changes (submit_pending runs before every use of the
 // stream).  Round 1 handed over in fixed batches of four behind one wait packet: 35.2 us/frame where this
 // gives 34.2 (same box), and at small frames 25 -> 20.5 us (800^2), 24.8 -> 22.4 (2048^2).
-constexpr int BATCH = LOOKAHEAD - 1;  // passes that may be pending (setup queued, tile kernel not yet)
+using tr::plan::BATCH;  // passes that may be pending (setup queued, tile kernel not yet)
 constexpr int RING = 16;  // events: pass p's are waited for until pass p + LOOKAHEAD is set up
 constexpr size_t ORDER_LISTS = 8;  // k_order's work lists per pass, n_tiles entries each (tr_kernels.hip)
 
@@ -141,8 +142,8 @@ constexpr size_t ORDER_LISTS = 8;  // k_order's work lists per pass, n_tiles ent
 // frame into a frame slot of its own (z, colour, fast-clear flags, shadow buffer).  Same replicated frame,
 // k_tile per frame (us, group of 1 / 2 / 4 / 8): 4096^2 phong 33.9 / 29.0 / 27.0 / 27.0, darboux 65.9 / 59.5 /
 // 58.9 / 56.3, 2048^2 phong 21.3 / 14.2 / 12.6 / 12.0, 800^2 26.3 / 12.8 / 7.4 / 4.5, 512^2 22.5 / 12.2 / 6.6 / 3.6.
-constexpr int GROUP_MAX = 32;   // frames per fused launch, at most
-constexpr int GROUP_SETS = 4;   // groups in flight: group g's setup reuses the bins of group g - GROUP_SETS
+using tr::plan::GROUP_MAX;   // frames per fused launch, at most
+using tr::plan::GROUP_SETS;  // groups in flight: group g's setup reuses the bins of group g - GROUP_SETS
 
 struct tr_scene {
     uint64_t id = 0;  // unique per scene of the process (who wrote a tr_host_alloc buffer last)
@@ -693,9 +694,7 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     HIP_TRY(hipMemcpy(&need, s->d_bin_need, sizeof need, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_bin_need, 0, sizeof need));
     HIP_TRY(hipStreamSynchronize(nullptr));  // (the scene's streams do not wait for the null stream)
-    uint64_t cap = s->pool_cap;
-    while (cap < need) cap *= 2;   // (need = the pairs the hungriest pass wanted)
-    if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
+    const uint64_t cap = plan::grown_pool(s->pool_cap, need);   // (need = the pairs the hungriest pass wanted)
     {
         // per-frame sets + the frame groups' sets, if they exist
         uint64_t sets = LOOKAHEAD;
@@ -713,7 +712,17 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
     }
     if (st != TR_OK) return st;
     // (the frame groups' bins follow bin_cap when their set is next used)
-    if (first_bad_seq < s->unreplayable_seq && first_bad_seq >= s->observed_seq) {
+    // what to do about the frame(s) that were rendered with too small a pool (tr_plan.h, overflow_action)
+    const PipelineDesc &pd = kPipelines[s->pipeline];
+    plan::OverflowState os;
+    os.first_bad_seq = first_bad_seq;
+    os.observed_seq = s->observed_seq;
+    os.unreplayable_seq = s->unreplayable_seq;
+    os.last_was_group = s->last_was_group;
+    os.last_valid = s->last.valid;
+    os.last_started_cleared = s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
+    switch (plan::overflow_action(os)) {
+    case plan::OverflowAction::REPORT_CALLERS_BUFFER: {
         char buf[320];
         snprintf(buf, sizeof buf,
                  "triangle bins overflowed in a frame that went to a caller's buffer and cannot be rendered again (an older "
@@ -721,7 +730,7 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
                  "frame; the pools have been grown to %u records per pass: render it again", s->pool_cap);
         return tr::fail(TR_E_BIN_OVERFLOW, buf);
     }
-    if (first_bad_seq < s->observed_seq) {
+    case plan::OverflowAction::REPORT_HANDED_ON: {
         char buf[320];
         snprintf(buf, sizeof buf,
                  "triangle bins overflowed in a frame that was already handed on (asynchronous read-back or caller's "
@@ -729,12 +738,14 @@ int recover_from_overflow(tr_scene *s, unsigned long long first_bad_seq)
                  "pass %llu of %llu): render it again", s->pool_cap, need, first_bad_seq, (unsigned long long)s->pass_seq);
         return tr::fail(TR_E_BIN_OVERFLOW, buf);
     }
-    if (s->last_was_group) return replay_tail(s);  // frames older than the tail no longer exist anywhere
-    const PipelineDesc &pd = kPipelines[s->pipeline];
-    const bool replayable = s->last.valid && s->last.z_fb_cleared && (pd.n_passes == 1 || s->last.shadow_cleared);
-    if (!replayable)
+    case plan::OverflowAction::REPLAY_TAIL:
+        return replay_tail(s);  // frames older than the tail no longer exist anywhere
+    case plan::OverflowAction::REPORT_ACCUMULATING:
         return tr::fail(TR_E_BIN_OVERFLOW,
                         "triangle bins overflowed during an accumulating render; they have been grown: clear and render again");
+    case plan::OverflowAction::REPLAY_LAST:
+        break;
+    }
     float keep[12];
     memcpy(keep, s->light, 12); memcpy(keep + 3, s->from, 12); memcpy(keep + 6, s->at, 12); memcpy(keep + 9, s->up, 12);
     memcpy(s->light, s->last.light, 12); memcpy(s->from, s->last.from, 12);
@@ -1044,12 +1055,15 @@ int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
     }
     // the library's own stream: see "Handing tile kernels to the main stream" above
     if (chain_on_main) return submit_front(s, false);  // its setup is ahead of it in the same queue
-    int status = TR_OK;
-    if ((int)s->pending.size() > BATCH) {
+    // (tr_plan.h, handover: the three cases of "Handing tile kernels to the main stream" above)
+    switch (plan::handover(s->pending.size(), s->tiles_submitted == 0,
+                           s->tiles_submitted != 0 && hipEventQuery(s->ev_tile[s->last_submitted_seq % RING]) == hipSuccess)) {
+    case plan::Handover::HOST_WAITS: {
         // steady state: the HOST waits for the oldest pending pass's setup (it completed long ago, or will
         // within microseconds: the setup stream runs ahead, and the main stream still holds the tile kernels
         // of the passes before it), then its tile kernel goes out with no wait packet in the GPU's queue.
         // This is also what keeps the host from running ahead of the GPU without bound.
+        int status = TR_OK;
         while ((int)s->pending.size() > BATCH) {
             HIP_TRY(hipEventSynchronize(s->ev_setup[s->pending.front().p_seq % RING]));
             int st2 = submit_front(s, false);
@@ -1057,10 +1071,13 @@ int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
         }
         return status;
     }
-    // start-up (the first passes after a sync): a main stream that has run dry gets the next tile kernel
-    // behind a wait packet (an idle GPU loses nothing to it) ...
-    if (s->tiles_submitted == 0 || hipEventQuery(s->ev_tile[s->last_submitted_seq % RING]) == hipSuccess)
+    case plan::Handover::FRONT_WITH_WAIT:
+        // start-up (the first passes after a sync): a main stream that has run dry gets the next tile kernel
+        // behind a wait packet (an idle GPU loses nothing to it) ...
         return submit_front(s, true);
+    case plan::Handover::READY_ONLY:
+        break;
+    }
     // ... otherwise whatever has its setup behind it goes out without one
     return submit_ready(s);
 }
@@ -1113,20 +1130,24 @@ int ensure_depth(tr_scene *s)
 // make the gap between launches small against the launch -- 32 K tiles (4096^2: 4 frames, 8 no better; 3072^2
 // 4 -> 8 frames 19.0 -> 18.1 us per frame, 2048^2 8 -> 16 10.4 -> 10.0, 1536^2 14 -> 28 7.2 -> 6.8), within
 // GROUP_MAX; at least four frames.  The winner tap and the tile stamps are single buffers: one frame.
-uint32_t group_size(const tr_scene *s)
+plan::SceneShape shape_of(const tr_scene *s)
 {
     static const int forced = getenv("TR_GROUP") ? atoi(getenv("TR_GROUP")) : 0;  // experiment hook
-    if (s->d_winner) return 1u;
-    if (forced >= 1 && forced <= GROUP_MAX) return s->max_slots && (uint32_t)forced > s->max_slots ? s->max_slots : (uint32_t)forced;
-    if (s->frames_per_launch) return s->frames_per_launch;  // (create() has checked it against max_frame_slots)
-    uint32_t g = s->n_tiles ? 32768u / s->n_tiles : (uint32_t)GROUP_MAX;
-    g = g < 4u ? 4u : g > (uint32_t)GROUP_MAX ? (uint32_t)GROUP_MAX : g;
-    // the sets of bins of the groups in flight stay below 48 GiB (a 16384^2 frame: 3 GiB of bins per pass)
-    const uint64_t per_frame = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * (uint64_t)kPipelines[s->pipeline].n_passes;
-    while (g > 1u && (uint64_t)GROUP_SETS * g * per_frame > (48ull << 30)) g--;
-    if (s->max_slots && g > s->max_slots) g = s->max_slots;
-    return g;
+    plan::SceneShape q;
+    q.n_tiles = s->n_tiles;
+    q.frames_per_launch = s->frames_per_launch;
+    q.max_slots = s->max_slots;
+    q.forced = forced > 0 ? (uint32_t)forced : 0u;
+    q.winner_tap = s->d_winner != nullptr;
+    q.tile_stamps = s->d_stamps != nullptr;
+    q.no_long_runs = s->no_long_runs;
+    q.n_passes = (uint32_t)kPipelines[s->pipeline].n_passes;
+    q.pool_bytes_per_pass = (uint64_t)s->pool_cap * s->rec_pieces * 16ull;
+    q.pixels = (uint64_t)s->width * s->height;
+    return q;
 }
+
+uint32_t group_size(const tr_scene *s) { return plan::group_size(shape_of(s)); }
 
 // Frames per launch that a LONG run of frames grows to (tr_scene_render_frames with sixteen groups or more; the
 // per-frame protocol after sixteen full groups in a row): between two tile kernels of a stream lie 6-12 us (the end of
@@ -1134,18 +1155,7 @@ uint32_t group_size(const tr_scene *s)
 // 4096^2 30.1 -> 28.7 us per frame.  Only when the group size is automatic, within 8 GiB of frame slots and 16 GiB of
 // record pools.  (Not for short runs: a slot's first frames are slower than its later ones -- 20 frames into 20 slots:
 // tile kernel 31.2 us per frame, into 4 slots used five times each: 29.1.)
-uint32_t long_run_group_size(const tr_scene *s)
-{
-    const uint32_t G = group_size(s);
-    if (s->d_winner || s->d_stamps || s->frames_per_launch || getenv("TR_GROUP") || s->no_long_runs) return G;
-    const uint64_t np = (uint64_t)kPipelines[s->pipeline].n_passes;
-    const uint64_t slot_bytes = (uint64_t)s->width * s->height * (4ull * np + 3ull);
-    const uint64_t set_bytes = (uint64_t)s->pool_cap * s->rec_pieces * 16ull * np;
-    uint32_t g = (uint32_t)GROUP_MAX;
-    while (g > G && (g * slot_bytes > (8ull << 30) || (uint64_t)GROUP_SETS * g * set_bytes > (16ull << 30))) g /= 2u;
-    if (s->max_slots && g > s->max_slots) g = s->max_slots;
-    return g < G ? G : g;
-}
+uint32_t long_run_group_size(const tr_scene *s) { return plan::long_run_group_size(shape_of(s)); }
 
 // Frame slots 1 .. n - 1 (slot 0 exists since tr_scene_create).  Their z memory needs no initial value:
 // a slot is only ever reached through a group's cleared frame, which writes every tile or raises its flag.
@@ -1574,24 +1584,21 @@ int flush_deferred(tr_scene *s, bool hold_back)
     tr_frame_params params[GROUP_MAX];
     void *fbs[GROUP_MAX];
     int slot_of[GROUP_MAX];
-    int next_slot = 0;
+    std::vector<const void *> wanted(g);
     for (uint32_t j = 0; j < g; j++) {
         params[j] = fr[j].p;
-        if (j + 1 == g) {
-            slot_of[j] = s->cur_slot;       // the frame the caller will see: the current targets
-            fbs[j] = fr[j].fb == s->slots[(size_t)s->cur_slot].fb ? nullptr : fr[j].fb;
-        } else {
-            if (next_slot == s->cur_slot) next_slot++;
-            slot_of[j] = next_slot++;
-            // its colour goes where the caller pointed render() unless a later frame of the group goes there
-            // too (then nobody can see it: the slot's own buffer)
-            bool overwritten = false;
-            for (uint32_t k = j + 1; k < g; k++) overwritten = overwritten || fr[k].fb == fr[j].fb;
-            fbs[j] = overwritten ? nullptr : fr[j].fb;
-            // (such a frame can be seen in its buffer but not rendered again: only the last frame is replayed)
-            if (fbs[j] && !own_frame_buffer(s, (const uint8_t *)fbs[j]))
-                s->unreplayable_seq = s->pass_seq + (uint64_t)(j + 1u) * (uint64_t)kPipelines[s->pipeline].n_passes;
-        }
+        wanted[j] = fr[j].fb;
+    }
+    // which slot and which colour target every frame gets (tr_plan.h, plan_deferred): the last one the current targets,
+    // the others -- which the per-frame protocol overwrites unobserved -- other slots
+    const std::vector<plan::DeferredTarget> targets = plan::plan_deferred(
+        wanted, s->cur_slot, s->slots[(size_t)s->cur_slot].fb, [s](const void *fb) { return own_frame_buffer(s, (const uint8_t *)fb); });
+    for (uint32_t j = 0; j < g; j++) {
+        slot_of[j] = targets[j].slot;
+        fbs[j] = const_cast<void *>(targets[j].fb);
+        // (such a frame can be seen in its buffer but not rendered again: only the last frame is replayed)
+        if (targets[j].unreplayable)
+            s->unreplayable_seq = s->pass_seq + (uint64_t)(j + 1u) * (uint64_t)kPipelines[s->pipeline].n_passes;
     }
     st = run_group(s, params, fbs, slot_of, g);
     if (st == TR_OK) st = hold_back ? submit_groups(s, false) : finish_groups(s);
@@ -1605,54 +1612,20 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
     if (st != TR_OK) return st;
     const uint32_t G = group_size(s);
     const uint32_t np = (uint32_t)kPipelines[s->pipeline].n_passes;
-    // The frames of a long call go out in groups of growing size (long_run_group_size): the first is the usual group
-    // (its tile kernel starts as early as it can), every later one up to four times the one before -- its setup chain
-    // still hides behind the tile kernel in front of it.
-    const uint32_t Gmax = n >= 16u * G ? long_run_group_size(s) : G;
-    static const uint32_t growth = [] {  // experiment hook (at least 2: a group must be able to grow)
-        const int v = getenv("TR_GROUP_GROWTH") ? atoi(getenv("TR_GROUP_GROWTH")) : 4;
-        return (uint32_t)(v < 2 ? 2 : v);
-    }();
-    std::vector<uint32_t> sizes;
-    uint32_t largest = 0;
-    // A SHORT call (fewer than sixteen groups) is mostly start-up and gaps: its first group is the usual one -- the host
-    // has four frames to prepare, not ten, before the first kernel can start, and the chain in front of the first tile
-    // kernel is the short one -- and every later group up to twice the one before (its chain hides behind the tile
-    // kernel in front), up to three times the usual size: twenty frames at 4096^2 = 4 + 8 + 8, two gaps instead of four.
-    static const uint32_t short_factor = [] {  // experiment hook (1 = the usual group throughout)
-        const int v = getenv("TR_SHORT_GROUPS") ? atoi(getenv("TR_SHORT_GROUPS")) : 3;
-        return (uint32_t)(v < 1 ? 1 : v);
-    }();
+    // The groups of the call, its frame slots, what every group set must hold (tr_plan.h, plan_call): a long call's
+    // groups grow, a short call's double from the usual one.
+    static const uint32_t growth = (uint32_t)(getenv("TR_GROUP_GROWTH") ? atoi(getenv("TR_GROUP_GROWTH")) : 4);      // experiment hooks
+    static const uint32_t short_factor = (uint32_t)(getenv("TR_SHORT_GROUPS") ? atoi(getenv("TR_SHORT_GROUPS")) : 3);  // (plan_call clamps them)
     const bool automatic = !s->d_winner && !s->d_stamps && !s->frames_per_launch && !getenv("TR_GROUP");
-    if (automatic && n > G && Gmax == G && short_factor > 1u) {
-        uint32_t cap = short_factor * G < (uint32_t)GROUP_MAX ? short_factor * G : (uint32_t)GROUP_MAX;
-        const uint32_t long_run = long_run_group_size(s);   // (slots and sets exist for that many: prepare_long_runs)
-        if (cap > long_run) cap = long_run;
-        for (uint32_t left = n, g = 0; left; left -= g) {
-            g = sizes.empty() ? G : (2u * g < cap ? 2u * g : cap);
-            // (the remainder in equal parts rather than a full group and a sliver)
-            const uint32_t parts = (left + g - 1u) / g;
-            g = (left + parts - 1u) / parts;
-            sizes.push_back(g);
-            largest = g > largest ? g : largest;
-        }
-    } else
-    for (uint32_t left = n, g = 0; left; left -= g) {
-        g = sizes.empty() ? G : (growth * g < Gmax ? growth * g : Gmax);
-        g = g < left ? g : left;
-        sizes.push_back(g);
-        largest = g > largest ? g : largest;
-    }
-    // frame slots of the call: frame i renders into slot i mod S (the last S frames stay distinct).  A long call's slots
-    // and sets are made for the largest group the policy can reach, not for this call's own: calls of 100 and of 2 000
-    // frames allocate the same
-    // (never fewer slots than the frames the call leaves behind: its last min(n, G))
-    const uint32_t S = Gmax > G ? Gmax : (largest > (n < G ? n : G) ? largest : (n < G ? n : G));
+    const plan::CallPlan cp = plan::plan_call(n, G, long_run_group_size(s), automatic, (int)growth < 2 ? 2u : growth,
+                                              (int)short_factor < 1 ? 1u : short_factor);
+    const std::vector<uint32_t> &sizes = cp.sizes;
+    const uint32_t S = cp.slots;
     if (n > G && (st = prepare_long_runs(s, fbs == nullptr)) != TR_OK) return st;
     if ((st = ensure_slots(s, S)) != TR_OK) return st;
     // all the sets of groups in flight now (allocations of a few hundred MiB each: not in the middle of a call)
     for (int k = 0; k < GROUP_SETS && !s->d_winner; k++)
-        if ((st = ensure_group_set(s, s->grp[k], largest > Gmax ? largest : Gmax)) != TR_OK) return st;
+        if ((st = ensure_group_set(s, s->grp[k], cp.set_frames)) != TR_OK) return st;
     s->host_status = TR_OK;
     const uint64_t first_seq = s->pass_seq;
     if (s->d_winner) {
@@ -1693,7 +1666,7 @@ int render_frames(tr_scene *s, uint32_t n, const tr_frame_params *p, void *const
         if ((st = use_slot(s, (int)((n - 1) % S), fbs ? (uint8_t *)fbs[n - 1] : nullptr)) != TR_OK) return st;
     }
     // what is left of the call: its last min(n, G) frames
-    const uint32_t kept = n < G ? n : G;
+    const uint32_t kept = cp.kept;
     s->tail.params.assign(p + (n - kept), p + n);
     s->tail.fbs.clear();
     if (fbs) s->tail.fbs.assign(fbs + (n - kept), fbs + n);
