@@ -579,6 +579,12 @@ __device__ __forceinline__ void write_cleared_tile(const TileArgs &a, int32_t ti
     }
 }
 
+// Keeps a wave-uniform value in scalar registers from this point on.  A member of the argument table is an invariant
+// scalar load the compiler prefers to REPEAT next to each use -- inside the shading loop that was 14 loads per step,
+// each with its own s_waitcnt (band rows four times, the texture's size, pitch and address twice): a round trip to
+// the scalar cache in the wave's serial path every few dozen instructions.  An empty asm makes the value opaque.
+#define TR_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+
 __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 {
     return __builtin_amdgcn_readlane((int)v, (int)lane);
@@ -757,7 +763,14 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const int32_t tx = (int32_t)(tile % a.frame.ntx);
     const int32_t ty = a.frame.ty_base + (int32_t)(tile / a.frame.ntx);
     const int32_t tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
-    const int32_t W = (int32_t)a.frame.width, H = (int32_t)a.frame.height;
+    int32_t W = (int32_t)a.frame.width, H = (int32_t)a.frame.height;
+    // what every shading step reads of the frame's arguments: into scalar registers once (TR_KEEP_SCALAR)
+    int32_t band_y0 = a.frame.band_y0, band_y1 = a.frame.band_y1;
+    uint32_t aligned4 = a.aligned4;
+    uint8_t *fb = a.fb;
+    DevTextures tex = a.tex;
+    TR_KEEP_SCALAR(W); TR_KEEP_SCALAR(H); TR_KEEP_SCALAR(band_y0); TR_KEEP_SCALAR(band_y1); TR_KEEP_SCALAR(aligned4); TR_KEEP_SCALAR(fb);
+    TR_KEEP_SCALAR(tex.packed); TR_KEEP_SCALAR(tex.packed_bpr); TR_KEEP_SCALAR(tex.w[0]); TR_KEEP_SCALAR(tex.h[0]);
     // the wave index is uniform: say so, so that quadrant bounds and the block loop stay scalar
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
 
@@ -798,7 +811,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 uint32_t zb = TR_F32_MIN_BITS;
                 if (!zfresh) {
                     const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
-                    if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
+                    if (px < W && py >= band_y0 && py < band_y1)
                         zb = __float_as_uint(depth[(size_t)py * W + px]);
                 }
                 wkey[shared_key_slot((uint32_t)((b % NBX) * 8 + lx), (uint32_t)((b / NBX) * 8 + ly))] =
@@ -810,7 +823,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 uint32_t zb = TR_F32_MIN_BITS;
                 if (!zfresh) {
                     const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
-                    if (px < W && py >= a.frame.band_y0 && py < a.frame.band_y1)
+                    if (px < W && py >= band_y0 && py < band_y1)
                         zb = __float_as_uint(depth[(size_t)py * W + px]);
                 }
                 wkey[(b << 6) + lane] = make_uint2(zb, 0u);
@@ -1126,7 +1139,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     // band give addresses that are formed but never used.
     float *const depth_strip = depth + ((int64_t)sy0 * W + sx0);
     uint32_t *const winner_strip = (!GROUP && a.winner) ? a.winner + ((int64_t)sy0 * W + sx0) : nullptr;
-    uint8_t *const fb_strip = DEPTH ? nullptr : a.fb + ((int64_t)(H - sy0 - STRIP_ROWS) * W + sx0) * 3;
+    uint8_t *const fb_strip = DEPTH ? nullptr : fb + ((int64_t)(H - sy0 - STRIP_ROWS) * W + sx0) * 3;
     const uint32_t Wu = (uint32_t)W, W3 = 3u * (uint32_t)W;
     const bool col_live = px < W;
 
@@ -1194,15 +1207,15 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 // the frame's lit texel image (k_lit): the closure has run for this texel already
                 uint32_t unused1, unused2;
                 vec3 unused3;
-                fetch_texels<FS>(a.tex, uu.x, vv.x, ea, ca, unused1, unused2, unused3);
-                fetch_texels<FS>(a.tex, uu.y, vv.y, eb, cb, unused1, unused2, unused3);
+                fetch_texels<FS>(tex, uu.x, vv.x, ea, ca, unused1, unused2, unused3);
+                fetch_texels<FS>(tex, uu.y, vv.y, eb, cb, unused1, unused2, unused3);
             } else if (FS == FS_DEFAULT || FS == FS_PHONG) {
                 // shader.rs:318-333 / 386-401 for both pixels at once: texel, diffuse term,
                 // color_blend(c, 0, t) = (t * c + (1 - t) * 0.0) as u8 per channel
                 uint32_t ta, tb, unused1, unused2;
                 vec3 unused3;
-                fetch_texels<FS>(a.tex, uu.x, vv.x, ea, ta, unused1, unused2, unused3);
-                fetch_texels<FS>(a.tex, uu.y, vv.y, eb, tb, unused1, unused2, unused3);
+                fetch_texels<FS>(tex, uu.x, vv.x, ea, ta, unused1, unused2, unused3);
+                fetch_texels<FS>(tex, uu.y, vv.y, eb, tb, unused1, unused2, unused3);
                 f2 t = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
                 if (FS == FS_PHONG)
                     t = dot3_2(bar.x, bar.y, bar.z, t, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
@@ -1226,7 +1239,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                         v[4 * i - 14] = __uint_as_float(piece.x); v[4 * i - 13] = __uint_as_float(piece.y);
                         v[4 * i - 12] = __uint_as_float(piece.z); v[4 * i - 11] = __uint_as_float(piece.w);
                     }
-                    return fragment_color<FS>(a.u, a.tex, v, b, u_, v_, (uint32_t)px_, (uint32_t)py_, z_, a.shadow,
+                    return fragment_color<FS>(a.u, tex, v, b, u_, v_, (uint32_t)px_, (uint32_t)py_, z_, a.shadow,
                                               (uint32_t)W, (uint32_t)H, e_, a.sclean);
                 };
                 if (PAIR) {
@@ -1244,7 +1257,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     bool bad_a, bad_b;
                     vec3p barp;
                     barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
-                    fragment_color_pair<FS>(a.u, a.tex, vary2, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
+                    fragment_color_pair<FS>(a.u, tex, vary2, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
                     if (__any((bad_a && won[0]) || (bad_b && won[1]))) {
                         redo = true;
                         ea = eb = 0u;  // the second run reports this step's lookups
@@ -1295,7 +1308,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         if (put && st_z) depth_strip[zoff] = zv;
         if (!DEPTH && st_c) {
             if (winner_strip && put && with_winner) winner_strip[zoff] = triv;
-            if (a.aligned4) {
+            if (aligned4) {
                 // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
                 // on, topped up from pixel p0+1
                 const uint32_t j = (uint32_t)hx;
@@ -1303,7 +1316,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 const uint32_t c0 = (uint32_t)__shfl((int)rgbv, (int)(half_base + (p0 & 31u)), 64);
                 const uint32_t c1 = (uint32_t)__shfl((int)rgbv, (int)(half_base + ((p0 + 1u) & 31u)), 64);
                 const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
-                const bool row_live = py_ >= a.frame.band_y0 && py_ < a.frame.band_y1;
+                const bool row_live = py_ >= band_y0 && py_ < band_y1;
                 if (j < 24u && row_live && (sx0 * 3 + (int32_t)(4u * j)) < W * 3)
                     *reinterpret_cast<uint32_t *>(fb_strip + (coff + 4u * j)) = dw;
             } else if (put) {
@@ -1333,7 +1346,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         for (int u = 0; u < 2; u++) {
             row[u] = sstep * 4 + u * 2 + hrow;  // within the strip
             py[u] = sy0 + row[u];
-            live[u] = col_live && py[u] >= a.frame.band_y0 && py[u] < a.frame.band_y1;
+            live[u] = col_live && py[u] >= band_y0 && py[u] < band_y1;
             const uint32_t s1 = survivor_slot((uint32_t)hx, (uint32_t)row[u]);
             won[u] = live[u] && s1 != 0u;
             wslot[u] = won[u] ? s1 - 1u : 0u;
