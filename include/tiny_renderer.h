@@ -29,7 +29,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define TR_ABI_VERSION 2
+#define TR_ABI_VERSION 3   /* 3: tr_options.max_frame_slots, TR_OPT_STORE_DEPTH, tr_exchange_set_ranges, 64 exchange slots */
 
 /* Status codes.  0 = ok, negative = failure (the reference panics at the cited site). */
 enum {

@@ -13,7 +13,7 @@ CONFIGS = [
 ]
 out = {}
 for name, flags in CONFIGS:
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--cpu-seconds", "3"] + flags
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--cpu-seconds", "3", "--no-configs"] + flags
     if "--steps" not in flags:
         cmd += ["--steps", "800", "--warmup", "64"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), "missing export: " + name
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     L = T.load_library()
-    assert L.tr_abi_version() == 2
+    assert L.tr_abi_version() == 3
     names = [L.tr_pipeline_name(i).decode() for i in range(L.tr_pipeline_count())]
     assert tuple(names) == T.PIPELINES  # shader.rs:100-109
 
