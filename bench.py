@@ -802,7 +802,9 @@ def main():
     if not closed_scene:
         driver.close()
     scale = None
-    if use_dist and world > 1 and not args.no_scale:
+    # (TR_BENCH_FORCE_SCALE=1 with TR_BENCH_FORCE_DIST=1: the leg with a single rank, a rehearsal of the RCCL transports'
+    # plumbing on a one-GPU box, where RCCL cannot have a second rank)
+    if use_dist and not args.no_scale and (world > 1 or os.environ.get("TR_BENCH_FORCE_SCALE") == "1"):
         scale = measure_scale_config(T, torch, dist, args, exchange_kind, rank, world, device_index)
     if out is not None:
         if scale is not None:

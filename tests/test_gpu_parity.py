@@ -1065,6 +1065,31 @@ def test_sharded_scene_two_ranks_one_gpu(built, exchange):
     assert r.returncode == 0 and "rank 0 OK" in r.stdout and "rank 1 OK" in r.stdout, (r.stdout[-1500:] + r.stderr[-4000:])
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "librccl"])
+def test_bench_sharded_path_over_rccl_with_one_rank(built, exchange):
+    """bench.py's N > 1 code path as the driver's multi-GPU run takes it -- process group, ShardedScene over torch's RCCL
+    collective (the default) or the library's own RCCL communicator, frame groups, per-rank timings, the scale_config
+    leg -- with the ONE rank RCCL allows on a one-GPU box (TR_BENCH_FORCE_DIST / TR_BENCH_FORCE_SCALE).  Two real ranks
+    run the same render side through the peer transports: test_sharded_scene_two_ranks_one_gpu."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TR_BENCH_FORCE_DIST="1", TR_BENCH_FORCE_SCALE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_PORT=str(29560 + (0 if exchange == "rccl" else 1)))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "1", "--exchange", exchange, "--size", "1024",
+                        "--steps", "12", "--warmup", "4", "--no-cpu", "--scale-size", "1024", "--scale-grid", "2", "--scale-steps", "8"],
+                       env=env, cwd=H.REPO, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["parity_vs_oracle"]["ok"] and j["group_ranks"] == 1 and "RCCL all-gather" in j["config"]["sharding"]
+    assert j["per_rank"][0]["band_rows"] == [0, 1024] and j["per_rank"][0]["render_us"] and j["per_rank"][0]["gather_us"]
+    sc = j["scale_config"]
+    assert sc["parity_vs_oracle"]["ok"] and "x4 grid" in sc["workload"] and sc["exchange"] == ("torch" if exchange == "rccl" else "rccl")
+
+
 def test_two_ranks_on_one_gpu_under_rccl_says_so(built):
     """`bench.py --gpus 2` with both ranks on this box's one GPU and the default (RCCL) exchange: one clear sentence, not
     RCCL's "Duplicate GPU detected" from the bottom of a traceback."""
