@@ -617,15 +617,62 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 #ifndef TR_WPE_DARBOUX_GROUP
 #define TR_WPE_DARBOUX_GROUP 5
 #endif
-constexpr int tile_waves_per_eu(int fs, int tile_waves, bool group = false)
+// Round 4: with the depth stores and the accumulate paths compiled out, the fused kernels of the light closures need
+// 62 vector registers -- and a wave of the tile kernel spends nine tenths of its life waiting (LDS, the staged bin, its
+// texels, two barriers): MORE waves per SIMD pay where round 1's register-starved kernels lost (seven: - 9 %).  What
+// limits a four-wave tile's workgroups per compute unit beyond six is LDS: 16 KiB of keys + 8 KiB of resident records;
+// with fewer resident records (lds_rec_bytes below: 72 at seven workgroups per CU, 40 at eight -- a tile of the reference's
+// model holds six on average at 4096^2; larger bins take the chunked path as before) seven or eight fit.  Same box, 4096^2,
+// k_tile per frame at 6 / 7 / 8: phong 25.3 / 23.9 / 23.6; shadow's colour pass 34.2 / 32.1 / 36.1 (64 registers: spills);
+// its depth pass 29.7 / 28.1 / 27.1.  Only four-wave tiles of fused launches: tiles with eight waves are at their LDS
+// limit already and lose registers (2048^2: 8.65 -> 9.05).
+#ifndef TR_WPE_LIGHT_GROUP
+#define TR_WPE_LIGHT_GROUP 8
+#endif
+#ifndef TR_WPE_SHADOW_GROUP
+#define TR_WPE_SHADOW_GROUP 7
+#endif
+#ifndef TR_WPE_DEPTH_GROUP
+#define TR_WPE_DEPTH_GROUP 8
+#endif
+#ifndef TR_WPE_LIT_GROUP
+#define TR_WPE_LIT_GROUP 8
+#endif
+// (the fetch-only fragment stage of the lit texel path: specular 4096^2, columns, 6 / 7 / 8: 30.1 / 29.2 / 28.7 us per step;
+// the x64 grid at 8192^2, SHARED resolve -- whose scan-line sums take another KiB of LDS, 31 resident records at eight --
+// 203.4 / 198.4 / 203.0: the shared resolve stops at seven)
+#ifndef TR_WPE_SHARED_MAX
+#define TR_WPE_SHARED_MAX 7
+#endif
+constexpr int tile_waves_per_eu(int fs, int tile_waves, bool group = false, bool shared = false)
 {
-    const int want = fs == FS_DARBOUX ? (group ? TR_WPE_DARBOUX_GROUP : TR_WPE_DARBOUX)
-                     : fs == FS_SPECULAR ? (group ? TR_WPE_SPECULAR_GROUP : TR_WPE_SPECULAR)
-                     : fs == FS_NORMAL_MAP ? TR_WPE_NORMAL_MAP : TR_WPE_LIGHT;
+    int want = fs == FS_DARBOUX ? (group ? TR_WPE_DARBOUX_GROUP : TR_WPE_DARBOUX)
+               : fs == FS_SPECULAR ? (group ? TR_WPE_SPECULAR_GROUP : TR_WPE_SPECULAR)
+               : fs == FS_NORMAL_MAP ? TR_WPE_NORMAL_MAP : TR_WPE_LIGHT;
+    if (group && tile_waves == 4) {
+        if (fs == FS_DEFAULT || fs == FS_PHONG) want = TR_WPE_LIGHT_GROUP;
+        if (fs == FS_SHADOW2) want = TR_WPE_SHADOW_GROUP;
+        if (fs == FS_DEPTH) want = TR_WPE_DEPTH_GROUP;
+        if (fs == FS_LIT) want = TR_WPE_LIT_GROUP;
+        if (shared && want > TR_WPE_SHARED_MAX) want = TR_WPE_SHARED_MAX;
+    }
     // sixteen waves per tile: a workgroup brings four waves to every SIMD, so 8 (two workgroups per
     // CU) or 4 (one) are the only useful budgets
     if (tile_waves == 16) return want >= 6 ? 8 : 4;
     return want;
+}
+// Bytes of a tile's bin that stay resident in LDS: what the workgroups of a compute unit leave of its 160 KiB beside
+// their keys (16 KiB) and, in the shared resolve, the scan-line sums (4 B per thread + per wave).  Four-wave tiles:
+// as many workgroups per CU as waves per SIMD.
+constexpr int lds_rec_bytes_for(int tile_waves, int waves_per_eu, bool shared)
+{
+    if (tile_waves != 4) return lds_rec_bytes(tile_waves);
+    // (a workgroup's share, rounded down to a multiple of 2 560 B: whatever the allocation granule -- 512 B, 1 280 B --
+    // the workgroups' rounded-up allocations then still fit)
+    const int per_wg = 160 * 1024 / waves_per_eu / 2560 * 2560;
+    const int left = per_wg - TILE_W * TILE_H * 8 - (shared ? 4 * 64 * tile_waves + 4 * tile_waves : 8) - 64;
+    const int cap = lds_rec_bytes(4);
+    return (left < cap ? left : cap) / 16 * 16;
 }
 
 // Keys of the SHARED resolve (below): one 64-bit word per pixel, compared as an unsigned integer by
@@ -663,7 +710,7 @@ __device__ __forceinline__ uint32_t depth_order_bits(float z)
 // visited once per tile instead of once per column it touches.
 #define TR_TILE_KERNEL_ATTRS \
     __global__ __launch_bounds__(64 * TILE_WAVES) \
-        __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES, MODE != 0), tile_waves_per_eu(FS, TILE_WAVES, MODE != 0))))
+        __attribute__((amdgpu_waves_per_eu(tile_waves_per_eu(FS, TILE_WAVES, MODE != 0, SHARED), tile_waves_per_eu(FS, TILE_WAVES, MODE != 0, SHARED))))
 
 // GROUP = false: one frame, arguments by value.
 // GROUP = true: a fused launch over a group of n_frames frames (tr_scene_render_frames): workgroup b renders
@@ -687,7 +734,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     static_assert(STRIP_ROWS % 4 == 0, "a shading step covers four rows");
     constexpr bool DEPTH = (FS == FS_DEPTH);
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
-    constexpr int NMAX = lds_rec_bytes(TILE_WAVES) / (P * 16);  // records resident in LDS
+    constexpr int NMAX = lds_rec_bytes_for(TILE_WAVES, tile_waves_per_eu(FS, TILE_WAVES, MODE != 0, SHARED), SHARED) / (P * 16);  // records resident in LDS
 
     // Per pixel, column mode: .x = z of the best fragment so far (f32 bits; compared as floats, so
     // -0.0 and +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what

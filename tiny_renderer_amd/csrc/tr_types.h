@@ -95,7 +95,10 @@ constexpr int REC_PIECES_LARGE = 9;  // 144 B
 // with more waves per tile are for frames whose tiles cannot fill the GPU; a CU holds three (8
 // waves) or two (16 waves) of their workgroups by wave count alone, so LDS is plentiful and the
 // heaviest tiles -- the critical path of a small frame -- stay resident (256 / 426 records).
-constexpr int lds_rec_bytes(int tile_waves) { return tile_waves == 4 ? 8192 : tile_waves == 8 ? 24576 : 40960; }
+#ifndef TR_LDS_REC4
+#define TR_LDS_REC4 8192
+#endif
+constexpr int lds_rec_bytes(int tile_waves) { return tile_waves == 4 ? TR_LDS_REC4 : tile_waves == 8 ? 24576 : 40960; }
 
 // Frame constants the kernels need, computed on the host by the prepares (shader.rs:183-279).
 struct DevUniforms {
