@@ -644,16 +644,27 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 #ifndef TR_WPE_SHARED_MAX
 #define TR_WPE_SHARED_MAX 7
 #endif
+// (occlusion's colour pass -- seventeen shadow-buffer lookups per fragment, 60 registers in the fused kernel: 6 / 7 / 8:
+// 191 / 180 / 171 us per frame at 4096^2; the per-frame kernels of the light closures, which hold their arguments in
+// registers: seven -- the unfused loop 34.2 -> 33.0)
+#ifndef TR_WPE_OCCL_GROUP
+#define TR_WPE_OCCL_GROUP 8
+#endif
+#ifndef TR_WPE_LIGHT4
+#define TR_WPE_LIGHT4 7
+#endif
 constexpr int tile_waves_per_eu(int fs, int tile_waves, bool group = false, bool shared = false)
 {
     int want = fs == FS_DARBOUX ? (group ? TR_WPE_DARBOUX_GROUP : TR_WPE_DARBOUX)
                : fs == FS_SPECULAR ? (group ? TR_WPE_SPECULAR_GROUP : TR_WPE_SPECULAR)
                : fs == FS_NORMAL_MAP ? TR_WPE_NORMAL_MAP : TR_WPE_LIGHT;
+    if (!group && tile_waves == 4 && fs != FS_DARBOUX && fs != FS_SPECULAR && fs != FS_NORMAL_MAP) want = TR_WPE_LIGHT4;
     if (group && tile_waves == 4) {
         if (fs == FS_DEFAULT || fs == FS_PHONG) want = TR_WPE_LIGHT_GROUP;
         if (fs == FS_SHADOW2) want = TR_WPE_SHADOW_GROUP;
         if (fs == FS_DEPTH) want = TR_WPE_DEPTH_GROUP;
         if (fs == FS_LIT) want = TR_WPE_LIT_GROUP;
+        if (fs == FS_OCCLUSION2) want = TR_WPE_OCCL_GROUP;
         if (shared && want > TR_WPE_SHARED_MAX) want = TR_WPE_SHARED_MAX;
     }
     // sixteen waves per tile: a workgroup brings four waves to every SIMD, so 8 (two workgroups per
