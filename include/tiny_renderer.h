@@ -285,6 +285,12 @@ int tr_scene_band_tiles(tr_scene *s, const void *frame_buffer_device, tr_band_ti
 int tr_exchange_all_gather_tiles(tr_exchange *x, uint32_t slot, const tr_band_tiles *tiles, void *hip_stream);
 int tr_exchange_status(tr_exchange *x);
 int tr_exchange_read(tr_exchange *x, uint32_t slot, void *host, size_t bytes); /* waits for the device, copies a slot out */
+/* Tearing a peer exchange down takes two steps when its ranks go on living (they create another exchange, say): a rank
+ * must not FREE slots a peer still has mapped (what HIP leaves undefined for exported memory), so every rank first
+ * unmaps its peers' slots and flags -- tr_exchange_disconnect: waits for the device, after which the exchange can only
+ * be destroyed --, the host's rendezvous confirms that all have (a barrier), and then each destroys its end.
+ * tr_exchange_destroy alone does both at once: fine when the process ends anyway. */
+int tr_exchange_disconnect(tr_exchange *x);
 void tr_exchange_destroy(tr_exchange *x);
 
 /* Diagnostic (TR_OPT_TILE_STAMPS): for each tile of the last colour pass {start, end} in 100 MHz
@@ -326,7 +332,9 @@ int tr_selftest_shadow_fetch(int device, uint32_t width, uint32_t height, const 
 /* Exhaustive device check of the kernels' own correctly rounded reciprocal (which = 0) and square
  * root (which = 1) for pixel pairs (csrc/tr_pk.h rcp2 / sqrt2: hardware estimate + fused residual
  * corrections) against the compiler's IEEE `1.0f / x` and `sqrtf`: every f32 with binary exponent in
- * [exp_lo, exp_hi].  n_bad counts differing results, bad_bits receives up to 16 of the arguments. */
+ * [exp_lo, exp_hi].  which = 2: the colour channels' cast-and-insert (v_cvt_pk_u8_f32) against the Rust `as u8` it
+ * stands for, x and -x; exp_lo = -127 .. exp_hi = 128 covers every f32 (zeros, subnormals, infinities, NaNs).
+ * n_bad counts differing results, bad_bits receives up to 16 of the arguments. */
 int tr_selftest_device_unary(int device, int which, int exp_lo, int exp_hi, uint64_t *n_tested, uint64_t *n_bad,
                              uint32_t bad_bits[16]);
 

@@ -951,7 +951,9 @@ def test_pair_rcp_sqrt_exhaustive(built):
     import ctypes as C
     import tiny_renderer_amd as T
     L = T.load_library()
-    for which, lo, hi in ((0, -42, 42), (1, -84, 84)):
+    # which = 2: pack_u8 (v_cvt_pk_u8_f32, the colour channels' `as u8` with its byte insertion) against f32_to_u8 for
+    # EVERY f32 -- subnormals, infinities and NaNs of both signs included (biased exponents 0..255, x and -x)
+    for which, lo, hi in ((0, -42, 42), (1, -84, 84), (2, -127, 128)):
         nt, nb = C.c_uint64(), C.c_uint64()
         bits = (C.c_uint32 * 16)()
         T._lib.check(L.tr_selftest_device_unary(0, which, lo, hi, C.byref(nt), C.byref(nb), bits))

@@ -129,6 +129,7 @@ SYMBOLS = {
     "tr_scene_band_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BandTiles)]),
     "tr_exchange_status": (C.c_int, [C.c_void_p]),
     "tr_exchange_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "tr_exchange_disconnect": (C.c_int, [C.c_void_p]),
     "tr_exchange_destroy": (None, [C.c_void_p]),
     "tr_selftest_device_unary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),

@@ -476,6 +476,24 @@ int tr_exchange_read(tr_exchange *x, uint32_t slot, void *host, size_t bytes)
     return tr_exchange_status(x);
 }
 
+int tr_exchange_disconnect(tr_exchange *x)
+{
+    if (!x) return tr::fail(TR_E_INVALID, "null exchange");
+    HIP_TRY(hipSetDevice(x->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (uint32_t p = 0; p < x->peer_flags.size(); p++) {
+        if (p == x->rank) continue;
+        if (x->peer_base.size() > p && x->peer_base[p]) (void)hipIpcCloseMemHandle(x->peer_base[p]);
+        if (x->peer_flags[p]) (void)hipIpcCloseMemHandle(x->peer_flags[p]);
+        if (x->peer_base.size() > p) x->peer_base[p] = nullptr;
+        x->peer_flags[p] = nullptr;
+        for (uint32_t s = 0; s < MAX_SLOTS; s++)
+            if (x->peer_frame[s].size() > p) x->peer_frame[s][p] = nullptr;
+    }
+    x->connected = false;
+    return TR_OK;
+}
+
 void tr_exchange_destroy(tr_exchange *x)
 {
     if (!x) return;

@@ -1282,8 +1282,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
-                    ca |= f32_to_u8(v.x) << (8 * ch);
-                    cb |= f32_to_u8(v.y) << (8 * ch);
+                    ca = pack_u8(v.x, (uint32_t)ch, ca);   // (`as u8` and the byte's place in one step, tr_math.h)
+                    cb = pack_u8(v.y, (uint32_t)ch, cb);
                 }
             } else {
                 // one pixel's closure after the other's (interleaved they need twice the registers)
@@ -1597,6 +1597,19 @@ __global__ __launch_bounds__(256) void k_selftest_unary(int which, uint32_t firs
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const float x = __uint_as_float(first + (uint32_t)i);
         float got, want;
+        if (which == 2) {
+            // pack_u8 (v_cvt_pk_u8_f32) against the cast it replaces, for x and -x, into every byte of a word
+            const uint32_t into = 0xA5C3E17Bu, b = (uint32_t)(i & 3u);
+            const uint32_t g0 = pack_u8(x, b, into), w0 = (into & ~(0xFFu << (8u * b))) | (f32_to_u8(x) << (8u * b));
+            const uint32_t g1 = pack_u8(-x, b, into), w1 = (into & ~(0xFFu << (8u * b))) | (f32_to_u8(-x) << (8u * b));
+            got = __uint_as_float(g0 ^ (g1 << 1) ^ (g1 >> 31));
+            want = __uint_as_float(w0 ^ (w1 << 1) ^ (w1 >> 31));
+            if (g0 != w0 || g1 != w1) {
+                const unsigned long long k = atomicAdd(n_bad, 1ull);
+                if (k < 16ull) bad_bits[k] = __float_as_uint(x);
+            }
+            continue;
+        }
         if (which == 0) {
             got = rcp2(mk2(x, -x)).x;
             want = 1.0f / x;

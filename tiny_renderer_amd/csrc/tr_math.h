@@ -106,6 +106,19 @@ TR_HD uint32_t f32_to_u8(float v)
     uint32_t r = f32_to_u32(v);
     return r < 255u ? r : 255u;
 }
+// `v as u8` into byte `byte` (0..3) of `into`, the other bytes kept: v_trunc_f32 + v_cvt_pk_u8_f32.  The conversion
+// saturates to 0..255 and takes NaN to 0 like the Rust cast, but ROUNDS to nearest (0.5023 -> 1: found by the exhaustive
+// check below), hence the truncation in front of it, after which it only sees integers.  Two instructions where
+// f32_to_u8 and the shift-or take three; compared with them for EVERY f32 on the device (tr_selftest_device_unary,
+// which = 2; tests/test_gpu_parity.py::test_pair_rcp_sqrt_exhaustive)
+TR_HD uint32_t pack_u8(float v, uint32_t byte, uint32_t into)
+{
+    uint32_t r;
+    float t;
+    asm("v_trunc_f32 %0, %1" : "=v"(t) : "v"(v));
+    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(byte), "v"(into));
+    return r;
+}
 #else
 TR_HD int32_t f32_to_i32(float v)
 {
@@ -127,6 +140,10 @@ TR_HD uint32_t f32_to_u8(float v)
     if (v >= 255.0f) return 255u;
     if (v <= 0.0f) return 0u;
     return (uint32_t)v;
+}
+TR_HD uint32_t pack_u8(float v, uint32_t byte, uint32_t into)
+{
+    return (into & ~(0xFFu << (8u * byte))) | (f32_to_u8(v) << (8u * byte));
 }
 #endif
 

@@ -2123,7 +2123,7 @@ int tr_selftest_shadow_fetch(int device, uint32_t width, uint32_t height, const 
 int tr_selftest_device_unary(int device, int which, int exp_lo, int exp_hi, uint64_t *n_tested, uint64_t *n_bad,
                              uint32_t bad_bits[16])
 {
-    if (!n_tested || !n_bad || !bad_bits || (which != 0 && which != 1) || exp_lo < -126 || exp_hi > 127 || exp_lo > exp_hi)
+    if (!n_tested || !n_bad || !bad_bits || which < 0 || which > 2 || exp_lo < -127 || exp_hi > 128 || exp_lo > exp_hi)
         return tr::fail(TR_E_INVALID, "bad argument");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     unsigned long long *d_n = nullptr;

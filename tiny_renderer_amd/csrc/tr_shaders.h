@@ -788,8 +788,8 @@ TR_HD void shade_blend_p(uint32_t ta, uint32_t tb, f2 t, uint32_t &ca, uint32_t 
     cb = 0u;
     for (int ch = 0; ch < 3; ch++) {
         const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
-        ca |= f32_to_u8(v.x) << (8 * ch);
-        cb |= f32_to_u8(v.y) << (8 * ch);
+        ca = pack_u8(v.x, (uint32_t)ch, ca);
+        cb = pack_u8(v.y, (uint32_t)ch, cb);
     }
 }
 

@@ -445,6 +445,14 @@ class PeerExchange:
         return int(self._L.tr_exchange_bytes_sent(self._h))
 
     def close(self):
+        """Collective when world > 1 (every rank closes its end): unmap the peers' slots, wait until everybody has
+        (nobody frees memory a peer still has mapped), then free."""
         if self._h:
+            self._check(self._L.tr_exchange_disconnect(self._h))
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.barrier()
             self._L.tr_exchange_destroy(self._h)
             self._h = None
+            if self.world > 1:
+                dist.barrier()   # (... and nobody exports new slots at an address a peer is still unmapping)
