@@ -406,6 +406,17 @@ extern "C" void tr_emul_div(int which, const float *x, const float *d, float *ou
                             : div_by2_nonzero(mk2(x[i], x[i]), mk2(d[i], d[i]), rcp2(mk2(d[i], d[i]))).y;
 }
 
+// color_blend(c, black, t) per channel: the product's form (tr_math.h blend_black: the (1 - t) * 0.0 term as a select)
+// and the literal one; returns the number of (t, c) pairs -- every channel value 0..255 -- whose bytes differ
+extern "C" uint64_t tr_emul_blend_mismatches(const float *t, uint64_t n)
+{
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++)
+        for (uint32_t c = 0; c < 256u; c++) bad += blend_black(c, t[i]) != blend_black_literal(c, t[i]);
+    return bad;
+}
+extern "C" uint32_t tr_emul_blend(uint32_t c, float t, int literal) { return literal ? blend_black_literal(c, t) : blend_black(c, t); }
+
 // decode_normal for two texels at once against the plain form; returns the number of differing components
 // shadow_fetch with fast-clear flags against the plain lookup in a fully materialised buffer: n lookups at
 // (x[i], y[i]); returns how many differ (value bits or error bits).

@@ -29,6 +29,10 @@ def lib():
         L.tr_emul_pair_counts.argtypes = [C.POINTER(C.c_uint64)]
         L.tr_emul_mask_counts.restype = None
         L.tr_emul_mask_counts.argtypes = [C.POINTER(C.c_uint64)]
+        L.tr_emul_blend_mismatches.restype = C.c_uint64
+        L.tr_emul_blend_mismatches.argtypes = [C.c_void_p, C.c_uint64]
+        L.tr_emul_blend.restype = C.c_uint32
+        L.tr_emul_blend.argtypes = [C.c_uint32, C.c_float, C.c_int]
         L.tr_emul_powf.restype = C.c_int
         L.tr_emul_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _lib = L

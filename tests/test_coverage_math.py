@@ -217,3 +217,32 @@ def test_darboux_third_column_only_matters_for_zero_sums():
     assert np.float32(0.0) < np.float32(2.0) ** np.float32(-40)
     # q finite: |cofactor| <= 2 (differences of products of unit-vector components), |det| >= 2^-40
     assert np.isfinite(np.float32(2.0) / np.float32(2.0) ** np.float32(-40))
+
+
+def test_blend_without_the_zero_term():
+    """util.rs:7-13 with color_2 = black: (t * c + (1 - t) * 0.0) as u8.  The product leaves the second term out and
+    replaces t = +inf by NaN instead (tr_math.h blend_black): identical bytes for every channel value 0..255 over the
+    special weights (zeros, infinities, NaNs, subnormals, the ends of the range, the neighbourhood of 1 and of k/255)
+    and a million random bit patterns -- and the literal form is what the oracle's tro_color_blend computes."""
+    Le = E.lib()
+    special = [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38,
+               255.0, 256.0, 1.0 / 255.0, 0.5, 0.99999994, 1.0000001, 2.0, 1e30, -1e30, 1.3e36, 1.4e36]
+    t = np.array(special, np.float32)
+    nan_payloads = np.array([0x7FC00001, 0xFFC00000, 0x7F800001, 0xFF800001], np.uint32).view(np.float32)
+    near = np.nextafter(np.float32(1.0) * np.arange(0, 256, dtype=np.float32) / np.float32(255.0), np.float32(2.0), dtype=np.float32)
+    rng = np.random.default_rng(5)
+    rnd = rng.integers(0, 2 ** 32, 1_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    t = np.ascontiguousarray(np.concatenate([t, nan_payloads, near, rnd]))
+    assert Le.tr_emul_blend_mismatches(t.ctypes.data, t.size) == 0
+    # the only weight for which the second term matters, and what it does there
+    assert Le.tr_emul_blend(200, np.inf, 1) == 0 and Le.tr_emul_blend(200, np.inf, 0) == 0
+    assert Le.tr_emul_blend(200, -np.inf, 1) == 0 and Le.tr_emul_blend(200, 3.0, 0) == 255
+    # the literal form against numpy's f32 arithmetic with Rust's saturating cast
+    c = np.arange(256, dtype=np.float32)
+    for tv in (0.3, 0.99999994, 1.0, 1.5, -0.2, 1e30):
+        tv = np.float32(tv)
+        with np.errstate(all="ignore"):
+            v = tv * c + (np.float32(1.0) - tv) * np.float32(0.0)
+        want = np.clip(np.trunc(np.nan_to_num(v, nan=0.0, posinf=255.0, neginf=0.0)), 0, 255).astype(np.uint32)
+        got = np.array([Le.tr_emul_blend(int(k), float(tv), 1) for k in range(256)], np.uint32)
+        assert np.array_equal(got, want)

@@ -653,6 +653,12 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 #ifndef TR_WPE_LIGHT4
 #define TR_WPE_LIGHT4 7
 #endif
+// Closures whose tile kernels run their per-pixel arithmetic on plain scalar pairs instead of packed ones (tr_pk.h, f2s):
+// a bit per FsKind.  The two-pixel closures are written for the packed type and stay packed.
+#ifndef TR_SCALAR_FS
+#define TR_SCALAR_FS ((1 << FS_DEFAULT) | (1 << FS_PHONG) | (1 << FS_LIT) | (1 << FS_SHADOW2))
+#endif
+constexpr bool tile_scalar_pairs(int fs) { return ((TR_SCALAR_FS) >> fs & 1) != 0 && !has_pair_closure(fs); }
 constexpr int tile_waves_per_eu(int fs, int tile_waves, bool group = false, bool shared = false)
 {
     int want = fs == FS_DARBOUX ? (group ? TR_WPE_DARBOUX_GROUP : TR_WPE_DARBOUX)
@@ -700,6 +706,10 @@ constexpr uint32_t SHARED_MAX_POLYGONS = 1u << 20, SHARED_MAX_SLOTS = 4093u;
 #ifndef TR_SCAN_ITEMS
 #define TR_SCAN_ITEMS 1
 #endif
+// (round 4: the survivor's key read whole, profiles/r04_notes.md)
+#ifndef TR_KEY_B64
+#define TR_KEY_B64 1
+#endif
 constexpr bool SCAN_ITEMS = TR_SCAN_ITEMS != 0;
 // Measurement builds only (wrong frames): leave a phase out to time the others (profiles/r03_notes.md)
 #ifndef TR_DBG_SKIP
@@ -746,6 +756,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     constexpr bool DEPTH = (FS == FS_DEPTH);
     constexpr int P = (FS == FS_DARBOUX) ? REC_PIECES_LARGE : REC_PIECES_SMALL;
     constexpr int NMAX = lds_rec_bytes_for(TILE_WAVES, tile_waves_per_eu(FS, TILE_WAVES, MODE != 0, SHARED), SHARED) / (P * 16);  // records resident in LDS
+    // the per-pixel arithmetic on plain pairs of scalars, or packed (tr_pk.h): per closure, measured
+    using V2 = std::conditional_t<tile_scalar_pairs(FS), f2s, f2>;
+    static_assert(!has_pair_closure(FS) || std::is_same<V2, f2>::value, "the two-pixel closures are written for the packed type");
 
     // Per pixel, column mode: .x = z of the best fragment so far (f32 bits; compared as floats, so
     // -0.0 and +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what
@@ -870,7 +883,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 if (!zfresh) {
                     const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
                     if (px < W && py >= band_y0 && py < band_y1)
-                        zb = __float_as_uint(depth[(size_t)py * W + px]);
+                        zb = __float_as_uint(gload(depth + ((size_t)py * W + px)));
                 }
                 wkey[shared_key_slot((uint32_t)((b % NBX) * 8 + lx), (uint32_t)((b / NBX) * 8 + ly))] =
                     make_uint2(PREV_TAG, depth_order_bits(__uint_as_float(zb)));
@@ -882,7 +895,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 if (!zfresh) {
                     const int32_t px = qx0 + (b % NBX) * 8 + lx, py = qy0 + (b / NBX) * 8 + ly;
                     if (px < W && py >= band_y0 && py < band_y1)
-                        zb = __float_as_uint(depth[(size_t)py * W + px]);
+                        zb = __float_as_uint(gload(depth + ((size_t)py * W + px)));
                 }
                 wkey[(b << 6) + lane] = make_uint2(zb, 0u);
             }
@@ -897,7 +910,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         for (uint32_t c0 = 0; c0 < n; c0 += NMAX) {
             const uint32_t m = min((uint32_t)NMAX, n - c0);
             if (c0 != 0u) __syncthreads();  // every wave is done with the previous chunk
-            for (uint32_t q = tid; q < m * P; q += (uint32_t)TILE_THREADS) s_rec[q] = bin[(size_t)c0 * P + q];
+            for (uint32_t q = tid; q < m * P; q += (uint32_t)TILE_THREADS) s_rec[q] = gload(bin + ((size_t)c0 * P + q));
             __syncthreads();
             if (stamps && c0 == 0u) t_staged = wall_clock64();
 
@@ -958,24 +971,24 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     const uint32_t id = (uint32_t)bcast(r3.y, l);
                     const uint32_t slot1 = SH ? c0 + j0 + l * (uint32_t)TILE_WAVES + wave + 1u : c0 + j0 + l + 1u;
                     uint32_t cols = (uint32_t)bcast(lmask, l);
-                    Edge2 e;
-                    e.a0 = splat2(__int_as_float(bcast(__float_as_uint(la0), l)));
-                    e.a1 = splat2(__int_as_float(bcast(__float_as_uint(la1), l)));
-                    e.b0 = splat2(__int_as_float(bcast(__float_as_uint(lb0), l)));
-                    e.b1 = splat2(__int_as_float(bcast(__float_as_uint(lb1), l)));
+                    Edge2T<V2> e;
+                    e.a0 = splat2v<V2>(__int_as_float(bcast(__float_as_uint(la0), l)));
+                    e.a1 = splat2v<V2>(__int_as_float(bcast(__float_as_uint(la1), l)));
+                    e.b0 = splat2v<V2>(__int_as_float(bcast(__float_as_uint(lb0), l)));
+                    e.b1 = splat2v<V2>(__int_as_float(bcast(__float_as_uint(lb1), l)));
                     const float cz = __int_as_float(bcast(__float_as_uint(lcz), l));
-                    e.cz = splat2(cz);
-                    e.y = splat2(__int_as_float(bcast(__float_as_uint(lry), l)));
+                    e.cz = splat2v<V2>(cz);
+                    e.y = splat2v<V2>(__int_as_float(bcast(__float_as_uint(lry), l)));
                     // this lane's two pixels: (px, pya) in block row 0 and (px, pyb) in block row 1
                     const int32_t pya = qy0 + ly, pyb = qy0 + 8 + ly;
-                    const f2 b2 = mk2((float)isub(y0, pya), (float)isub(y0, pyb));
+                    const V2 b2 = mk2v<V2>((float)isub(y0, pya), (float)isub(y0, pyb));
                     // the inside test (scene.rs:245-247 on to_barycentric_coord's cross products, divided
                     // by cross.z > 0): cross.x >= 0, cross.y >= 0, cross.x + cross.y <= cross.z.  The last is
                     // taken as cross.z - (cross.x + cross.y) >= 0 (same truth value: a difference of two
                     // floats has the sign of the exact difference) so that one three-way minimum and one
                     // compare decide a pixel; a row outside the clamped box gets -inf for cross.z.
                     const bool rowa = pya >= by0 && pya <= by1, rowb = pyb >= by0 && pyb <= by1;
-                    const f2 czp = mk2(rowa ? cz : -__builtin_inff(), rowb ? cz : -__builtin_inff());
+                    const V2 czp = mk2v<V2>(rowa ? cz : -__builtin_inff(), rowb ? cz : -__builtin_inff());
                     while (cols) {
                         const int32_t ib = (int32_t)__builtin_ctz(cols);
                         cols &= cols - 1u;
@@ -986,9 +999,9 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                         const uint2 cur_a = *slot_a, cur_b = *slot_b;
                         const int32_t px = qx0 + ib * 8 + lx;
                         const bool inx = (uint32_t)isub(px, bx0) <= (uint32_t)isub(bx1, bx0);
-                        f2 cx, cy;
-                        edge_cross2(e, splat2((float)isub(x0, px)), b2, cx, cy);
-                        const f2 rest = czp - (cx + cy);
+                        V2 cx, cy;
+                        edge_cross2(e, splat2v<V2>((float)isub(x0, px)), b2, cx, cy);
+                        const V2 rest = czp - (cx + cy);
                         const bool hita = inx && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
                         const bool hitb = inx && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
                         if (SH) {
@@ -996,8 +1009,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                                 // shared keys: the candidate (depth order bits, tie-break word) against what the
                                 // pixel holds now -- a plain read, possibly stale, but keys only grow, so a
                                 // candidate that does not beat it can never win -- then one atomic maximum
-                                const Bary2 bar = barycentric2_for_compare(cx, cy, e);
-                                const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
+                                const Bary2T<V2> bar = barycentric2_for_compare(cx, cy, e);
+                                const V2 z = dot3_2(bar.x, bar.y, bar.z, splat2v<V2>(z0), splat2v<V2>(z1), splat2v<V2>(z2));
                                 const uint32_t tag = (((SHARED_MAX_POLYGONS - 1u) - id) << 12) | slot1;
                                 const unsigned long long ka = ((unsigned long long)depth_order_bits(z.x) << 32) | tag;
                                 const unsigned long long kb = ((unsigned long long)depth_order_bits(z.y) << 32) | tag;
@@ -1013,8 +1026,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                         } else if (hita || hitb) {
                             // depth of both fragments; only compared here (the survivor's stored z is
                             // recomputed with exact zero signs when it is shaded)
-                            const Bary2 bar = barycentric2_for_compare(cx, cy, e);
-                            const f2 z = dot3_2(bar.x, bar.y, bar.z, splat2(z0), splat2(z1), splat2(z2));
+                            const Bary2T<V2> bar = barycentric2_for_compare(cx, cy, e);
+                            const V2 z = dot3_2(bar.x, bar.y, bar.z, splat2v<V2>(z0), splat2v<V2>(z1), splat2v<V2>(z2));
                             // both comparisons first, branch-free, so that the two key reads above are
                             // consumed together after the arithmetic; equal depths (shared vertices and
                             // edges, or the buffer's previous content) are the rare divergent path
@@ -1032,7 +1045,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                                     bool w = DEPTH;
                                     if (cs != 0u) {
                                         const uint32_t cur_id = resident ? s_rec[(cs - 1u) * P + 3].y
-                                                                         : bin[(size_t)(cs - 1u) * P + 3].y;
+                                                                         : gload(bin + ((size_t)(cs - 1u) * P + 3)).y;
                                         w = DEPTH ? id > cur_id : id < cur_id;
                                     }
                                     if (h == 0) wina = w; else winb = w;
@@ -1124,12 +1137,12 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                         }
                         const int32_t x0 = (int32_t)q1.x;
                         const float bf = (float)isub((int32_t)q1.y, py);
-                        const f2 a1b = splat2(a1 * bf), a0b = splat2(a0 * bf);  // e.a1 * b2, e.a0 * b2 of edge_cross2
-                        Edge2 e;
-                        e.cz = splat2(cz);
-                        e.y = splat2(yv);
-                        const f2 z0 = splat2(__uint_as_float(q2.z)), z1 = splat2(__uint_as_float(q2.w));
-                        const f2 z2 = splat2(__uint_as_float(q3.x));
+                        const V2 a1b = splat2v<V2>(a1 * bf), a0b = splat2v<V2>(a0 * bf);  // e.a1 * b2, e.a0 * b2 of edge_cross2
+                        Edge2T<V2> e;
+                        e.cz = splat2v<V2>(cz);
+                        e.y = splat2v<V2>(yv);
+                        const V2 z0 = splat2v<V2>(__uint_as_float(q2.z)), z1 = splat2v<V2>(__uint_as_float(q2.w));
+                        const V2 z2 = splat2v<V2>(__uint_as_float(q3.x));
                         const uint32_t tag = (((SHARED_MAX_POLYGONS - 1u) - q3.y) << 12) | (c0 + rec + 1u);
                         const uint32_t yrel = (uint32_t)isub(py, qy0) & (uint32_t)(TILE_H - 1);
                         const uint32_t xrel = (uint32_t)isub(xs, qx0) & (uint32_t)(TILE_W - 2);
@@ -1140,14 +1153,14 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                             uint4 *const slot = reinterpret_cast<uint4 *>(wkey + (key_row + (kx ^ key_sw)));
                             const uint4 cur = *slot;
                             const int32_t px = xs + 2 * k;
-                            const f2 a2 = mk2((float)isub(x0, px), (float)isub(x0, px + 1));
-                            const f2 cx = a1b - a2 * splat2(b1), cy = a2 * splat2(b0) - a0b;
-                            const f2 rest = e.cz - (cx + cy);
+                            const V2 a2 = mk2v<V2>((float)isub(x0, px), (float)isub(x0, px + 1));
+                            const V2 cx = a1b - a2 * splat2v<V2>(b1), cy = a2 * splat2v<V2>(b0) - a0b;
+                            const V2 rest = e.cz - (cx + cy);
                             const bool hita = ((inmask >> (2 * k)) & 1u) && __builtin_fminf(__builtin_fminf(cx.x, cy.x), rest.x) >= 0.0f;
                             const bool hitb = ((inmask >> (2 * k + 1)) & 1u) && __builtin_fminf(__builtin_fminf(cx.y, cy.y), rest.y) >= 0.0f;
                             if (hita || hitb) {
-                                const Bary2 bar = barycentric2_for_compare(cx, cy, e);
-                                const f2 z = dot3_2(bar.x, bar.y, bar.z, z0, z1, z2);
+                                const Bary2T<V2> bar = barycentric2_for_compare(cx, cy, e);
+                                const V2 z = dot3_2(bar.x, bar.y, bar.z, z0, z1, z2);
                                 const unsigned long long ka = ((unsigned long long)depth_order_bits(z.x) << 32) | tag;
                                 const unsigned long long kb = ((unsigned long long)depth_order_bits(z.y) << 32) | tag;
                                 const unsigned long long ca_ = ((unsigned long long)cur.y << 32) | cur.x;
@@ -1208,7 +1221,16 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             const uint32_t f = s_key[shared_key_slot((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)].x & 0xFFFu;
             return (f == 0xFFFu) ? 0u : f;
         }
+        // (the whole 8-byte key: 64 lanes x 8 bytes in a row are conflict-free as ds_read_b64, the upper dwords alone as
+        // ds_read_b32 are a two-way bank conflict)
+#if TR_KEY_B64
+        const uint2 key = s_key[key_slot<QUAD_COLUMN>((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)];
+        uint32_t keep = key.x;
+        asm volatile("" : "+v"(keep));   // (keeps the compiler from narrowing the read again)
+        return key.y;
+#else
         return s_key[key_slot<QUAD_COLUMN>((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)].y;
+#endif
     };
     // Two pixels of a lane through the fragment stage, each against its own polygon: pixel u at (pxs[u], pys[u]),
     // survivor in bin slot wslot[u] if won[u].  Lanes without a survivor run the same loads on record 0 and
@@ -1232,35 +1254,36 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         const uint4 *const rb = RESIDENT ? s_rec + mul24(wslot[1], (uint32_t)P) : bin + (size_t)wslot[1] * P;
 #pragma unroll
         for (int i = 1; i < TOP; i++) {
-            qa[i] = ra[i];
-            qb[i] = rb[i];
+            qa[i] = RESIDENT ? ra[i] : gload(ra + i);
+            qb[i] = RESIDENT ? rb[i] : gload(rb + i);
         }
-        const uint32_t rya = P > TOP ? ra[P - 1].w : qa[TOP - 1].w, ryb = P > TOP ? rb[P - 1].w : qb[TOP - 1].w;
+        const uint32_t rya = P > TOP ? (RESIDENT ? ra[P - 1].w : gload(ra + (P - 1)).w) : qa[TOP - 1].w;
+        const uint32_t ryb = P > TOP ? (RESIDENT ? rb[P - 1].w : gload(rb + (P - 1)).w) : qb[TOP - 1].w;
         // to_barycentric_coord for both pixels (each against its own polygon)
-        Edge2 e;
-        e.a0 = mk2(__uint_as_float(qa[1].z), __uint_as_float(qb[1].z));
-        e.a1 = mk2(__uint_as_float(qa[2].x), __uint_as_float(qb[2].x));
-        e.b0 = mk2(__uint_as_float(qa[1].w), __uint_as_float(qb[1].w));
-        e.b1 = mk2(__uint_as_float(qa[2].y), __uint_as_float(qb[2].y));
+        Edge2T<V2> e;
+        e.a0 = mk2v<V2>(__uint_as_float(qa[1].z), __uint_as_float(qb[1].z));
+        e.a1 = mk2v<V2>(__uint_as_float(qa[2].x), __uint_as_float(qb[2].x));
+        e.b0 = mk2v<V2>(__uint_as_float(qa[1].w), __uint_as_float(qb[1].w));
+        e.b1 = mk2v<V2>(__uint_as_float(qa[2].y), __uint_as_float(qb[2].y));
         e.cz = e.a0 * e.b1 - e.a1 * e.b0;
-        e.y = mk2(__uint_as_float(rya), __uint_as_float(ryb));
-        const f2 a2 = mk2((float)isub((int32_t)qa[1].x, pxs[0]), (float)isub((int32_t)qb[1].x, pxs[1]));
-        const f2 b2 = mk2((float)isub((int32_t)qa[1].y, pys[0]), (float)isub((int32_t)qb[1].y, pys[1]));
-        f2 cx, cy;
+        e.y = mk2v<V2>(__uint_as_float(rya), __uint_as_float(ryb));
+        const V2 a2 = mk2v<V2>((float)isub((int32_t)qa[1].x, pxs[0]), (float)isub((int32_t)qb[1].x, pxs[1]));
+        const V2 b2 = mk2v<V2>((float)isub((int32_t)qa[1].y, pys[0]), (float)isub((int32_t)qb[1].y, pys[1]));
+        V2 cx, cy;
         edge_cross2(e, a2, b2, cx, cy);
-        const Bary2 bar = barycentric2(cx, cy, e);
-        const f2 z = dot3_2(bar.x, bar.y, bar.z, mk2(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
-                            mk2(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
-                            mk2(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
+        const Bary2T<V2> bar = barycentric2(cx, cy, e);
+        const V2 z = dot3_2(bar.x, bar.y, bar.z, mk2v<V2>(__uint_as_float(qa[2].z), __uint_as_float(qb[2].z)),
+                            mk2v<V2>(__uint_as_float(qa[2].w), __uint_as_float(qb[2].w)),
+                            mk2v<V2>(__uint_as_float(qa[3].x), __uint_as_float(qb[3].x)));
         uint32_t ca = 0u, cb = 0u, ea = 0u, eb = 0u;
         if (!DEPTH && st_c) {   // (a depth-only repeat of a colour pass: the z, no closure)
             // uv = vertex_uvs * bar (2x3 gemv), both pixels
-            f2 uu = mk2(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
-            f2 vv = mk2(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
-            uu = mk2(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
-            vv = mk2(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
-            uu = mk2(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
-            vv = mk2(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
+            V2 uu = mk2v<V2>(__uint_as_float(qa[3].z), __uint_as_float(qb[3].z)) * bar.x;
+            V2 vv = mk2v<V2>(__uint_as_float(qa[3].w), __uint_as_float(qb[3].w)) * bar.x;
+            uu = mk2v<V2>(__uint_as_float(qa[4].x), __uint_as_float(qb[4].x)) * bar.y + uu;
+            vv = mk2v<V2>(__uint_as_float(qa[4].y), __uint_as_float(qb[4].y)) * bar.y + vv;
+            uu = mk2v<V2>(__uint_as_float(qa[4].z), __uint_as_float(qb[4].z)) * bar.z + uu;
+            vv = mk2v<V2>(__uint_as_float(qa[4].w), __uint_as_float(qb[4].w)) * bar.z + vv;
             if (FS == FS_LIT) {
                 // the frame's lit texel image (k_lit): the closure has run for this texel already
                 uint32_t unused1, unused2;
@@ -1274,14 +1297,22 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 vec3 unused3;
                 fetch_texels<FS>(tex, uu.x, vv.x, ea, ta, unused1, unused2, unused3);
                 fetch_texels<FS>(tex, uu.y, vv.y, eb, tb, unused1, unused2, unused3);
-                f2 t = mk2(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
+                V2 t = mk2v<V2>(__uint_as_float(qa[5].x), __uint_as_float(qb[5].x));
                 if (FS == FS_PHONG)
-                    t = dot3_2(bar.x, bar.y, bar.z, t, mk2(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
-                               mk2(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
-                const f2 k = (splat2(1.0f) - t) * splat2(0.0f);
+                    t = dot3_2(bar.x, bar.y, bar.z, t, mk2v<V2>(__uint_as_float(qa[5].y), __uint_as_float(qb[5].y)),
+                               mk2v<V2>(__uint_as_float(qa[5].z), __uint_as_float(qb[5].z)));
+#if TR_BLEND_FAST
+                t = mk2v<V2>(blend_weight(t.x), blend_weight(t.y));  // (blend_black, tr_math.h: the (1 - t) * 0.0 term as a select)
+#else
+                const V2 k = (splat2v<V2>(1.0f) - t) * splat2v<V2>(0.0f);
+#endif
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+#if TR_BLEND_FAST
+                    const V2 v = t * mk2v<V2>((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu));
+#else
+                    const V2 v = t * mk2v<V2>((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+#endif
                     ca = pack_u8(v.x, (uint32_t)ch, ca);   // (`as u8` and the byte's place in one step, tr_math.h)
                     cb = pack_u8(v.y, (uint32_t)ch, cb);
                 }
@@ -1293,29 +1324,30 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     v[0] = __uint_as_float(q[3].z); v[1] = __uint_as_float(q[3].w);
 #pragma unroll
                     for (int i = 4; i < P; i++) {
-                        const uint4 piece = i < TOP ? q[i] : rec[i];
+                        const uint4 piece = i < TOP ? q[i] : (RESIDENT ? rec[i] : gload(rec + i));
                         v[4 * i - 14] = __uint_as_float(piece.x); v[4 * i - 13] = __uint_as_float(piece.y);
                         v[4 * i - 12] = __uint_as_float(piece.z); v[4 * i - 11] = __uint_as_float(piece.w);
                     }
                     return fragment_color<FS>(a.u, tex, v, b, u_, v_, (uint32_t)px_, (uint32_t)py_, z_, a.shadow,
                                               (uint32_t)W, (uint32_t)H, e_, a.sclean);
                 };
-                if (PAIR) {
+                if constexpr (PAIR) {
                     // both pixels through the closure together in packed arithmetic with shared
                     // reciprocals (tr_shaders.h, fragment_color_pair); a step in which a surviving pixel's
                     // operands leave the range that form is proven on is run again with the plain
                     // closure (rare: exact zeros among the normalised components, a degenerate basis)
                     auto vary2 = [&](int k) -> f2 {
                         const int i = k < 2 ? 3 : (k + 14) / 4, c = k < 2 ? k + 2 : (k + 14) % 4;
-                        const uint4 pa = i < TOP ? qa[i] : ra[i], pb = i < TOP ? qb[i] : rb[i];
+                        const uint4 pa = i < TOP ? qa[i] : (RESIDENT ? ra[i] : gload(ra + i)), pb = i < TOP ? qb[i] : (RESIDENT ? rb[i] : gload(rb + i));
                         const uint32_t wa = c == 0 ? pa.x : c == 1 ? pa.y : c == 2 ? pa.z : pa.w;
                         const uint32_t wb = c == 0 ? pb.x : c == 1 ? pb.y : c == 2 ? pb.z : pb.w;
                         return mk2(__uint_as_float(wa), __uint_as_float(wb));
                     };
                     bool bad_a, bad_b;
                     vec3p barp;
-                    barp.x = bar.x; barp.y = bar.y; barp.z = bar.z;
-                    fragment_color_pair<FS>(a.u, tex, vary2, barp, uu, vv, ca, cb, ea, eb, bad_a, bad_b);
+                    // (V2 is f2 wherever this branch is instantiated; the conversions keep its text well-formed elsewhere)
+                    barp.x = to_f2(bar.x); barp.y = to_f2(bar.y); barp.z = to_f2(bar.z);
+                    fragment_color_pair<FS>(a.u, tex, vary2, barp, to_f2(uu), to_f2(vv), ca, cb, ea, eb, bad_a, bad_b);
                     if (__any((bad_a && won[0]) || (bad_b && won[1]))) {
                         redo = true;
                         ea = eb = 0u;  // the second run reports this step's lookups
@@ -1357,15 +1389,15 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
             // untouched pixel of an accumulate render: its colour may share a dword with a
             // touched neighbour, so fetch it
             const uint8_t *old = fb_strip + (coff + 3u * (uint32_t)hx);
-            rgbv = pack_rgb(old[0], old[1], old[2]);
+            rgbv = pack_rgb(gload(old), gload(old + 1), gload(old + 2));
         }
         // depth: only pixels that changed (or every live pixel of a fresh tile)
         const bool put = live && (won || zfresh);
         // (TileArgs::store: a cleared frame's colour pass may leave its depth on the chip -- nothing reads the z buffer
         // of such a frame unless a getter or an accumulating render asks, and then the pass is repeated for the depth alone)
-        if (put && st_z) depth_strip[zoff] = zv;
+        if (put && st_z) gstore(depth_strip + zoff, zv);
         if (!DEPTH && st_c) {
-            if (winner_strip && put && with_winner) winner_strip[zoff] = triv;
+            if (winner_strip && put && with_winner) gstore(winner_strip + zoff, triv);
             if (aligned4) {
                 // dword j of the 96-byte row = bytes 4j..4j+3 = pixel p0 = 4j/3 from byte (4j)%3
                 // on, topped up from pixel p0+1
@@ -1376,12 +1408,12 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                 const uint32_t dw = (c0 >> (8u * o)) | (c1 << (24u - 8u * o));
                 const bool row_live = py_ >= band_y0 && py_ < band_y1;
                 if (j < 24u && row_live && (sx0 * 3 + (int32_t)(4u * j)) < W * 3)
-                    *reinterpret_cast<uint32_t *>(fb_strip + (coff + 4u * j)) = dw;
+                    gstore(reinterpret_cast<uint32_t *>(fb_strip + (coff + 4u * j)), dw);
             } else if (put) {
                 uint8_t *p = fb_strip + (coff + 3u * (uint32_t)hx);
-                p[0] = (uint8_t)(rgbv & 0xFFu);
-                p[1] = (uint8_t)((rgbv >> 8) & 0xFFu);
-                p[2] = (uint8_t)((rgbv >> 16) & 0xFFu);
+                gstore(p, (uint8_t)(rgbv & 0xFFu));
+                gstore(p + 1, (uint8_t)((rgbv >> 8) & 0xFFu));
+                gstore(p + 2, (uint8_t)((rgbv >> 16) & 0xFFu));
             }
         }
     };

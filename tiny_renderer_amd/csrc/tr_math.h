@@ -147,6 +147,37 @@ TR_HD uint32_t pack_u8(float v, uint32_t byte, uint32_t into)
 }
 #endif
 
+// Loads and stores through the GLOBAL address space.  Pointers that come out of an argument table in memory are
+// generic to the compiler, which then emits flat_load / flat_store: a 64-bit vector address per access (an extra
+// two-slot v_lshl_add_u64), both the vector-memory and the LDS counter to wait for, and an aperture check per access.
+// Everything these helpers touch lives in device (or mapped host) memory, never in LDS or scratch.
+#ifndef TR_GLOBAL_AS
+#define TR_GLOBAL_AS 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && TR_GLOBAL_AS
+template <typename T>
+TR_HD T gload(const T *p)
+{
+    return *(const __attribute__((address_space(1))) T *)p;
+}
+template <typename T>
+TR_HD void gstore(T *p, T v)
+{
+    *(__attribute__((address_space(1))) T *)p = v;
+}
+#else
+template <typename T>
+TR_HD T gload(const T *p)
+{
+    return *p;
+}
+template <typename T>
+TR_HD void gstore(T *p, T v)
+{
+    *p = v;
+}
+#endif
+
 // a * b for operands below 2^24 (texture and frame dimensions, record slots): one full-rate
 // instruction on the device, where a 32 x 32 bit multiply takes four.
 TR_HD uint32_t mul24(uint32_t a, uint32_t b)
@@ -184,9 +215,30 @@ TR_HD float div_by(float x, Recip r)
     return x == 0.0f ? q0 : q;  // the residual form turns -0/d into +0; the product keeps the sign
 }
 
-// util.rs:7-13 with color_2 = (0,0,0), one channel: (t*c + (1-t)*0.0) as u8.  The second term
-// is kept: it turns t = +-inf into NaN -> 0 like the reference.
+// util.rs:7-13 with color_2 = (0,0,0), one channel: (t*c + (1-t)*0.0) as u8.  The second term is a zero for every
+// finite t (either sign: added to a non-zero product it changes nothing, added to a zero product the sum is a zero,
+// and every zero casts to 0) and NaN for t = +-inf and NaN, which makes the channel 0.  Without it NaN and -inf give
+// 0 anyway (NaN -> 0; -inf * c is -inf or NaN -> 0), and only t = +inf differs (+inf * c = +inf -> 255 for c > 0).
+// So: the weight with +inf replaced by NaN, times the channel -- a compare and a select per PIXEL where the second
+// term cost two operations per pixel and an addition per channel (tests/test_coverage_math.py::
+// test_blend_without_the_zero_term compares both forms for every channel value over the special and 10^6 random weights).
+#ifndef TR_BLEND_FAST
+#define TR_BLEND_FAST 1
+#endif
+TR_HD float blend_weight(float t)
+{
+    return t == __builtin_inff() ? __builtin_nanf("") : t;
+}
 TR_HD uint32_t blend_black(uint32_t c, float t)
+{
+#if TR_BLEND_FAST
+    return f32_to_u8(blend_weight(t) * (float)c);
+#else
+    return f32_to_u8(t * (float)c + (1.0f - t) * 0.0f);
+#endif
+}
+// (the literal form, for the test that compares the two)
+TR_HD uint32_t blend_black_literal(uint32_t c, float t)
 {
     return f32_to_u8(t * (float)c + (1.0f - t) * 0.0f);
 }

@@ -12,40 +12,63 @@
 
 namespace tr {
 
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float f2 __attribute__((ext_vector_type(2)));
-TR_HD f2 mk2(float a, float b)
-{
-    f2 r;
-    r.x = a;
-    r.y = b;
-    return r;
-}
-TR_HD f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-#else
-struct f2 {
+// f2s: the same two components as a plain struct -- every operation one scalar instruction per component.  A packed
+// f32 instruction occupies the vector ALU for two issue slots on this machine (measured: v_pk_fma_f32 1.9 ns per
+// wave-instruction and SIMD, v_fma_f32 1.0), so packing saves instructions, not cycles, and costs register moves
+// wherever the two pixels' operands do not already sit in an aligned register pair (the survivors' records of the
+// shading step: 32 v_mov per step) plus the even alignment of every pair.  The tile kernels of the light closures run
+// their per-pixel arithmetic on f2s (k_tile, tile_scalar_pairs): 59 vector registers and no spills where the packed
+// form needs 64 and spills three, 24.4 -> 22.4 us per frame at 4096^2 phong; the two-pixel closures (normal map,
+// specular, darboux), whose long dependent chains of normalisations gain from the halved instruction count, stay
+// packed (darboux 46.4 -> 49.7 us per frame as scalars).  The library is built -fno-slp-vectorize, or the compiler
+// packs the scalar form again.  (profiles/r04_notes.md)
+struct f2s {
     float x, y;
 };
-TR_HD f2 mk2(float a, float b)
+template <class V>
+TR_HD V mk2v(float a, float b)
 {
-    f2 r;
+    V r;
     r.x = a;
     r.y = b;
     return r;
 }
-TR_HD f2 operator+(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
-TR_HD f2 operator-(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
-TR_HD f2 operator*(f2 a, f2 b) { return mk2(a.x * b.x, a.y * b.y); }
-TR_HD f2 operator-(f2 a) { return mk2(-a.x, -a.y); }
-TR_HD f2 fma2(f2 a, f2 b, f2 c) { return mk2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
-#endif
+TR_HD f2s operator+(f2s a, f2s b) { return mk2v<f2s>(a.x + b.x, a.y + b.y); }
+TR_HD f2s operator-(f2s a, f2s b) { return mk2v<f2s>(a.x - b.x, a.y - b.y); }
+TR_HD f2s operator*(f2s a, f2s b) { return mk2v<f2s>(a.x * b.x, a.y * b.y); }
+TR_HD f2s operator-(f2s a) { return mk2v<f2s>(-a.x, -a.y); }
+TR_HD f2s fma2(f2s a, f2s b, f2s c) { return mk2v<f2s>(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TR_NO_PK)
+#define TR_F2_PACKED 1
+typedef float f2 __attribute__((ext_vector_type(2)));
+TR_HD f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+#define TR_F2_PACKED 0
+typedef f2s f2;
+#endif
+TR_HD f2 mk2(float a, float b) { return mk2v<f2>(a, b); }
+
+template <class V>
+TR_HD V splat2v(float a)
+{
+    return mk2v<V>(a, a);
+}
 TR_HD f2 splat2(float a) { return mk2(a, a); }
+template <class V>
+TR_HD f2 to_f2(V v)
+{
+    return mk2(v.x, v.y);
+}
 
 // The signed-zero repair of div_by as one bit operation: q0 = x * y always carries the sign of the
 // quotient (no underflow here: |x| >= 1 or x = 0, |y| >= 2^-62), and the corrected q differs from it
 // in sign only when x is a zero.
-TR_HD f2 quotient_sign_from(f2 q, f2 q0) { return mk2(copysignf(q.x, q0.x), copysignf(q.y, q0.y)); }
+template <class V>
+TR_HD V quotient_sign_from(V q, V q0)
+{
+    return mk2v<V>(copysignf(q.x, q0.x), copysignf(q.y, q0.y));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Correctly rounded 1/d and sqrt(s) for two values at once.  The device forms start from the
@@ -94,6 +117,10 @@ TR_HD f2 div_by2_nonzero(f2 x, f2 d, f2 y)
 }
 
 // (a.x*b.x + a.y*b.y) + a.z*b.z per component, the dot3 order
-TR_HD f2 dot3_2(f2 ax, f2 ay, f2 az, f2 bx, f2 by, f2 bz) { return (ax * bx + ay * by) + az * bz; }
+template <class V>
+TR_HD V dot3_2(V ax, V ay, V az, V bx, V by, V bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
 
 }  // namespace tr

@@ -358,57 +358,64 @@ TR_HD float record_recip(const RasterRec &r) { return 1.0f / edge_setup(r).cz; }
 
 // Two pixels at once (same polygon in coverage, possibly different ones in shading): the raw
 // cross products of scene.rs:178-187 per component.
-struct Edge2 {
-    f2 a0, a1, b0, b1, cz, y;
+template <class V>
+struct Edge2T {
+    V a0, a1, b0, b1, cz, y;
 };
+using Edge2 = Edge2T<f2>;
 
-TR_HD void edge_cross2(const Edge2 &e, f2 a2, f2 b2, f2 &cx, f2 &cy)
+template <class V>
+TR_HD void edge_cross2(const Edge2T<V> &e, V a2, V b2, V &cx, V &cy)
 {
     cx = e.a1 * b2 - a2 * e.b1;
     cy = a2 * e.b0 - e.a0 * b2;
 }
 
-struct Bary2 {
-    f2 x, y, z;
+template <class V>
+struct Bary2T {
+    V x, y, z;
 };
+using Bary2 = Bary2T<f2>;
 
 // Barycentrics whose zeros may carry the wrong sign (the residual corrections turn a -0 / d into +0
 // and the repair is skipped): good for the depth comparison of the coverage loop, where +0 and -0
 // are the same value, not for values that are stored.
-TR_HD Bary2 barycentric2_for_compare(f2 cx, f2 cy, const Edge2 &e)
+template <class V>
+TR_HD Bary2T<V> barycentric2_for_compare(V cx, V cy, const Edge2T<V> &e)
 {
     // the three shared-reciprocal quotients (div_by, tr_math.h) advanced in lockstep: each step's three
     // operations are independent, so no dependent packed operation issues back to back
-    const f2 s = cx + cy;
-    const f2 q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
-    f2 es = fma2(-q0s, e.cz, s), ex = fma2(-q0x, e.cz, cx), ey = fma2(-q0y, e.cz, cy);
-    f2 qs = fma2(es, e.y, q0s), qx = fma2(ex, e.y, q0x), qy = fma2(ey, e.y, q0y);
+    const V s = cx + cy;
+    const V q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
+    V es = fma2(-q0s, e.cz, s), ex = fma2(-q0x, e.cz, cx), ey = fma2(-q0y, e.cz, cy);
+    V qs = fma2(es, e.y, q0s), qx = fma2(ex, e.y, q0x), qy = fma2(ey, e.y, q0y);
     es = fma2(-qs, e.cz, s);
     ex = fma2(-qx, e.cz, cx);
     ey = fma2(-qy, e.cz, cy);
-    Bary2 b;
-    b.x = splat2(1.0f) - fma2(es, e.y, qs);
+    Bary2T<V> b;
+    b.x = splat2v<V>(1.0f) - fma2(es, e.y, qs);
     b.y = fma2(ex, e.y, qx);
     b.z = fma2(ey, e.y, qy);
     return b;
 }
 
-TR_HD Bary2 barycentric2(f2 cx, f2 cy, const Edge2 &e)
+template <class V>
+TR_HD Bary2T<V> barycentric2(V cx, V cy, const Edge2T<V> &e)
 {
     // div_by2 for the three numerators in lockstep (see barycentric2_for_compare), here with the
     // sign of a zero quotient kept: these values are stored and shaded
-    const f2 s = cx + cy;
-    const f2 q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
-    f2 es = fma2(-q0s, e.cz, s), ex = fma2(-q0x, e.cz, cx), ey = fma2(-q0y, e.cz, cy);
-    f2 qs = fma2(es, e.y, q0s), qx = fma2(ex, e.y, q0x), qy = fma2(ey, e.y, q0y);
+    const V s = cx + cy;
+    const V q0s = s * e.y, q0x = cx * e.y, q0y = cy * e.y;
+    V es = fma2(-q0s, e.cz, s), ex = fma2(-q0x, e.cz, cx), ey = fma2(-q0y, e.cz, cy);
+    V qs = fma2(es, e.y, q0s), qx = fma2(ex, e.y, q0x), qy = fma2(ey, e.y, q0y);
     es = fma2(-qs, e.cz, s);
     ex = fma2(-qx, e.cz, cx);
     ey = fma2(-qy, e.cz, cy);
     qs = fma2(es, e.y, qs);
     qx = fma2(ex, e.y, qx);
     qy = fma2(ey, e.y, qy);
-    Bary2 b;
-    b.x = splat2(1.0f) - quotient_sign_from(qs, q0s);
+    Bary2T<V> b;
+    b.x = splat2v<V>(1.0f) - quotient_sign_from(qs, q0s);
     b.y = quotient_sign_from(qx, q0x);
     b.z = quotient_sign_from(qy, q0y);
     return b;
@@ -430,7 +437,7 @@ TR_HD uint32_t fetch_texel(const DevTextures &tex, int which, int dims, float u,
         cx = cx >= tex.w[which] ? tex.w[which] - 1u : cx;
         cy = cy >= tex.h[which] ? tex.h[which] - 1u : cy;
     }
-    return tex.texel[which][mul24(cy, tex.w[which]) + cx];  // sides are below 2^16 (checked at create)
+    return gload(tex.texel[which] + (mul24(cy, tex.w[which]) + cx));  // sides are below 2^16 (checked at create)
 }
 
 // util.rs:51-56
@@ -471,10 +478,10 @@ TR_HD bool fetch_texels(const DevTextures &tex, float u, float v, uint32_t &err,
         }
         const uint32_t at = packed_index(K, tex.packed_bpr, cx, cy);
         if (K == 1) {
-            t0 = tex.packed[at];
+            t0 = gload(tex.packed + at);
             return false;
         }
-        const Texel4 q = reinterpret_cast<const Texel4 *>(tex.packed)[at];
+        const Texel4 q = gload(reinterpret_cast<const Texel4 *>(tex.packed) + at);
         t0 = q.x & 0xFFFFFFu;
         t2 = q.x >> 24;
         n = make3(bits_f32(q.y), bits_f32(q.z), bits_f32(q.w));
@@ -526,10 +533,10 @@ TR_HD float shadow_fetch(const float *shadow, const uint32_t *sclean, uint32_t W
             iy = idx / W;
             ix = idx - iy * W;
         }
-        if (sclean[(iy / (uint32_t)TILE_H) * ((W + (uint32_t)TILE_W - 1u) / (uint32_t)TILE_W) + ix / (uint32_t)TILE_W] != 0u)
+        if (gload(sclean + ((iy / (uint32_t)TILE_H) * ((W + (uint32_t)TILE_W - 1u) / (uint32_t)TILE_W) + ix / (uint32_t)TILE_W)) != 0u)
             return bits_f32(TR_F32_MIN_BITS);
     }
-    return shadow[idx];
+    return gload(shadow + idx);
 }
 
 // Runs fragment closure `FS` for a fragment whose depth test has already passed.
@@ -783,11 +790,19 @@ TR_HD vec3p transform_normal_p(const float *m, vec3p n, PairGuard &g)
 // color_blend(c, 0, t) for one pixel of a pair, channels from a packed texel (shade_blend)
 TR_HD void shade_blend_p(uint32_t ta, uint32_t tb, f2 t, uint32_t &ca, uint32_t &cb)
 {
-    const f2 k = (splat2(1.0f) - t) * splat2(0.0f);
+#if TR_BLEND_FAST
+    const f2 w = mk2(blend_weight(t.x), blend_weight(t.y));  // (blend_black, tr_math.h: the (1 - t) * 0.0 term as a select)
+#else
+    const f2 w = t, k = (splat2(1.0f) - t) * splat2(0.0f);
+#endif
     ca = 0u;
     cb = 0u;
     for (int ch = 0; ch < 3; ch++) {
-        const f2 v = t * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+#if TR_BLEND_FAST
+        const f2 v = w * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu));
+#else
+        const f2 v = w * mk2((float)((ta >> (8 * ch)) & 0xFFu), (float)((tb >> (8 * ch)) & 0xFFu)) + k;
+#endif
         ca = pack_u8(v.x, (uint32_t)ch, ca);
         cb = pack_u8(v.y, (uint32_t)ch, cb);
     }
