@@ -317,7 +317,12 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_setup_group(const SetupArgs *
 template <int P>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_bin_group(const SetupArgs *__restrict__ table, uint32_t polys)
 {
-    bin_body<P>(*(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y), blockIdx.x, polys);
+    const SetupArgs &a = *(const SetupArgs *)((constant_ptr<SetupArgs>)table + blockIdx.y);
+    // the pass's list lengths (k_order has completed) to the host, which sizes later tile kernels' grids by them
+    constexpr uint32_t N_LISTS = 8u;  // (ORDER_BUCKETS, below)
+    if (blockIdx.x == 0u && threadIdx.x < N_LISTS && a.len_host)
+        __hip_atomic_store(a.len_host + threadIdx.x, gload(a.len_src + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bin_body<P>(a, blockIdx.x, polys);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -384,6 +389,14 @@ __global__ __launch_bounds__(256) void k_lit_group(const SetupArgs *__restrict__
 constexpr int ORDER_BUCKETS = 8;
 constexpr int ORDER_THREADS = 256;
 constexpr int ORDER_EMPTY = ORDER_BUCKETS - 1;  // the list of the tiles without polygons
+static_assert(ORDER_BUCKETS == 8, "k_bin_group reports eight list lengths");
+// The tile kernel's WORK UNITS: one per tile with polygons (lists 0..6, heaviest first), then one per EMPTY_CHUNK
+// entries of the empty list.  A workgroup per EMPTY tile -- three quarters of a 4096^2 frame of the reference's model --
+// is four waves and 20 KiB of LDS dispatched to read one flag: 3.3 of a frame's 22.8 us went into dispatching them
+// (measured with a grid cut behind the busy tiles, profiles/r04_notes.md).  A launch needs
+// units(lengths) = busy + ceil(empty / EMPTY_CHUNK) workgroups per frame; any larger grid is correct (the surplus
+// exits at once), n_tiles always suffices, and a host that knows the lengths (SetupArgs::len_host) asks for no more.
+constexpr uint32_t EMPTY_CHUNK = 32u;
 
 // Bijection on [0, n): odd multiplications and xor-shifts are bijections on [0, 2^bits); values
 // that fall outside [0, n) are walked through the same map again (cycle walking).
@@ -654,11 +667,11 @@ __device__ __forceinline__ int32_t bcast(uint32_t v, uint32_t lane)
 #define TR_WPE_LIGHT4 7
 #endif
 // Closures whose tile kernels run their per-pixel arithmetic on plain scalar pairs instead of packed ones (tr_pk.h, f2s):
-// a bit per FsKind.  The two-pixel closures are written for the packed type and stay packed.
+// a bit per FsKind (coverage, barycentrics, uv; a two-pixel closure itself is written for the packed type and stays packed).
 #ifndef TR_SCALAR_FS
-#define TR_SCALAR_FS ((1 << FS_DEFAULT) | (1 << FS_PHONG) | (1 << FS_LIT) | (1 << FS_SHADOW2))
+#define TR_SCALAR_FS ((1 << FS_DEFAULT) | (1 << FS_PHONG) | (1 << FS_LIT) | (1 << FS_SHADOW2) | (1 << FS_NORMAL_MAP) | (1 << FS_SPECULAR))
 #endif
-constexpr bool tile_scalar_pairs(int fs) { return ((TR_SCALAR_FS) >> fs & 1) != 0 && !has_pair_closure(fs); }
+constexpr bool tile_scalar_pairs(int fs) { return ((TR_SCALAR_FS) >> fs & 1) != 0; }
 constexpr int tile_waves_per_eu(int fs, int tile_waves, bool group = false, bool shared = false)
 {
     int want = fs == FS_DARBOUX ? (group ? TR_WPE_DARBOUX_GROUP : TR_WPE_DARBOUX)
@@ -758,7 +771,6 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     constexpr int NMAX = lds_rec_bytes_for(TILE_WAVES, tile_waves_per_eu(FS, TILE_WAVES, MODE != 0, SHARED), SHARED) / (P * 16);  // records resident in LDS
     // the per-pixel arithmetic on plain pairs of scalars, or packed (tr_pk.h): per closure, measured
     using V2 = std::conditional_t<tile_scalar_pairs(FS), f2s, f2>;
-    static_assert(!has_pair_closure(FS) || std::is_same<V2, f2>::value, "the two-pixel closures are written for the packed type");
 
     // Per pixel, column mode: .x = z of the best fragment so far (f32 bits; compared as floats, so
     // -0.0 and +0.0 tie exactly like the reference's `z <= zbuf`), .y = its bin slot + 1 (0 = "what
@@ -779,7 +791,6 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     // letting the busy blocks issue those stores themselves, was 5-10 % slower (profiles/r01_notes.md); fewer
     // workgroups that each take several tiles (a loop around this body) cost registers -- 7-13 spilled
     // vector registers in the light closures' kernels -- and 4-12 % (profiles/r03_notes.md).  Any order is correct.
-    const uint32_t tid = threadIdx.x;
     const uint32_t n_fr = GROUP ? n_frames : 1u;
     const uint32_t frame_of_group = blockIdx.x % n_fr;
     // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
@@ -790,6 +801,12 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const bool st_z = FS == FS_DEPTH || (MODE == 0 ? (a.store & TR_STORE_DEPTH) != 0u : MODE == 1);
     const bool st_c = FS == FS_DEPTH || MODE != 0 || (a.store & TR_STORE_COLOR) != 0u;
     const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
+    // Work units (EMPTY_CHUNK above): workgroup blockIdx / frames of a frame takes that unit.  (A loop that lets a
+    // workgroup take further units -- so that ANY grid would do and the host could size it by an estimate -- costs the
+    // body registers it does not have: 48-68 bytes of spills per lane in the light closures' kernels, 22.7 -> 29.1 us per
+    // frame with one workgroup per tile and 23.6 with the estimate; profiles/r04_notes.md.  So the grid is exact or full.)
+    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_stale[EMPTY_CHUNK];  // empty chunk: tile + 1 of the chunk's tiles whose colour must be written, else 0
     uint32_t entry = blockIdx.x / n_fr;
     uint32_t list = 0u;
     {
@@ -806,11 +823,43 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         }
     }
     uint64_t *const stamps = frame_of_group == 0u ? a.stamps : nullptr;  // the diagnostic stamps follow a group's first frame
+    if (list == (uint32_t)ORDER_EMPTY) {
+        // ---- a chunk of the empty list: EMPTY_CHUNK tiles without polygons (work unit `entry` behind the busy tiles) ----
+        constant_ptr<uint32_t> lens = GROUP ? (constant_ptr<uint32_t>)a.list_len : (constant_ptr<uint32_t>)a.tile_count + n_tiles;
+        const uint32_t n_empty = lens[ORDER_EMPTY], first = entry * EMPTY_CHUNK;
+        if (first >= n_empty || !fresh) return;  // (surplus workgroup of a grid sized for the worst case; an accumulating render leaves empty tiles alone)
+        const uint32_t cnt = min(EMPTY_CHUNK, n_empty - first);
+        // An empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory already holds them
+        // (it was empty the last time it was written, too: most of a frame, most of the time); its z stays unwritten
+        // behind the tile's fast-clear flag (depth passes write their f32::MIN).  (A pass that leaves the colour or the
+        // depth out -- TileArgs::store -- leaves the respective memory and flags of the tile alone.)
+        uint32_t my_tile = 0u;
+        bool my_stale = false;
+        if (tid < cnt) {
+            my_tile = a.order[(size_t)ORDER_EMPTY * n_tiles + first + tid].tile;
+            my_stale = st_c && (DEPTH ? a.zclean == nullptr : (a.fbclean == nullptr || gload(a.fbclean + my_tile) == 0u));
+            s_stale[tid] = my_stale ? my_tile + 1u : 0u;
+        }
+        // (every flag has been read before the first one is raised)
+        __syncthreads();
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t t1 = s_stale[i];
+            if (t1 == 0u) continue;
+            const uint32_t t = t1 - 1u;
+            write_cleared_tile<DEPTH, TILE_THREADS, !GROUP>(a, (int32_t)(t % a.frame.ntx) * TILE_W,
+                                      (a.frame.ty_base + (int32_t)(t / a.frame.ntx)) * TILE_H, a.zclean == nullptr);
+        }
+        if (tid < cnt) {
+            if (!DEPTH && my_stale && a.fbclean) a.fbclean[my_tile] = 1u;
+            if (a.zclean && st_z) a.zclean[my_tile] = 1u;
+        }
+        return;
+    }
     const WorkItem work = a.order[(size_t)list * n_tiles + entry];
     const uint32_t tile = work.tile;
     uint32_t n = work.count;
     // (k_bin has counted the tile's counter down to the start of its range; the set's next pass counts from zero)
-    if (tid == 0u && list != (uint32_t)ORDER_EMPTY) a.tile_count[tile] = 0u;
+    if (tid == 0u) a.tile_count[tile] = 0u;
     if (n == 0u) {
         if (fresh) {
             // an empty tile of a cleared frame: its colour is zeros -- stored unless the tile's memory
@@ -1345,7 +1394,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     };
                     bool bad_a, bad_b;
                     vec3p barp;
-                    // (V2 is f2 wherever this branch is instantiated; the conversions keep its text well-formed elsewhere)
+                    // (the two-pixel closures are written for the packed type)
                     barp.x = to_f2(bar.x); barp.y = to_f2(bar.y); barp.z = to_f2(bar.z);
                     fragment_color_pair<FS>(a.u, tex, vary2, barp, to_f2(uu), to_f2(vv), ca, cb, ea, eb, bad_a, bad_b);
                     if (__any((bad_a && won[0]) || (bad_b && won[1]))) {
@@ -1878,6 +1927,8 @@ template <int WAVES, bool SHARED>
 static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames,
                              hipStream_t st, hipEvent_t start, hipEvent_t done)
 {
+    // (n_tiles here: the workgroups per frame -- the frame's tiles, or the work units a host that knows the lists'
+    // lengths asks for, tile_work_units)
     const dim3 grid(n_tiles * (group ? n_frames : 1u)), block(64 * WAVES);
     // (a fused launch whose frames leave their depth on the chip: `a` -- what the group's frames have in common -- says so)
     const bool transient = group && fs != FS_DEPTH && a.store == TR_STORE_COLOR;
@@ -1907,11 +1958,20 @@ static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const 
     return 0;
 }
 
-int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
-                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done)
+uint32_t tile_work_units(const uint32_t lengths[8])
 {
-    const uint32_t n_tiles = a.frame.ntx * a.frame.nty;
+    uint32_t busy = 0u;
+    for (int b = 0; b < ORDER_EMPTY; b++) busy += lengths[b];
+    return busy + (lengths[ORDER_EMPTY] + EMPTY_CHUNK - 1u) / EMPTY_CHUNK;
+}
+
+int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
+                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done, uint32_t units_per_frame)
+{
+    uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
+    // workgroups per frame: one per tile always suffices (units <= tiles); fewer when the caller knows the lists' lengths
+    if (units_per_frame != 0u && units_per_frame < n_tiles) n_tiles = units_per_frame;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || (uint64_t)n_tiles * n_frames > 0x7FFFFFFFull)) return (int)hipErrorInvalidValue;
     // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns

@@ -144,6 +144,7 @@ constexpr size_t ORDER_LISTS = 8;  // k_order's work lists per pass, n_tiles ent
 // 58.9 / 56.3, 2048^2 phong 21.3 / 14.2 / 12.6 / 12.0, 800^2 26.3 / 12.8 / 7.4 / 4.5, 512^2 22.5 / 12.2 / 6.6 / 3.6.
 using tr::plan::GROUP_MAX;   // frames per fused launch, at most
 using tr::plan::GROUP_SETS;  // groups in flight: group g's setup reuses the bins of group g - GROUP_SETS
+constexpr size_t LEN_WORDS = 8;  // a pass's words in GroupSet::h_lens: its eight list lengths
 
 struct tr_scene {
     uint64_t id = 0;  // unique per scene of the process (who wrote a tr_host_alloc buffer last)
@@ -267,6 +268,10 @@ struct tr_scene {
         int tile_waves[2] = { 4, 4 }, shared[2] = { 0, 0 };  // the tile kernels' layout, per pass (decided with the setup)
         bool chain_on_main = false;        // its setup was queued on the main stream itself (nothing was in flight)
         uint32_t *lit = nullptr;           // [frame] x lit_words: the frames' lit texel images (scenes with the lit path)
+        // [pass][frame] x 8 words, page-locked and mapped: the list lengths of the passes this set last held
+        // (k_bin_group writes them; group_units sizes later tile kernels' grids by them)
+        volatile uint32_t *h_lens = nullptr;
+        uint32_t *d_lens = nullptr;
     } grp[GROUP_SETS];
     uint64_t group_seq = 0;       // groups whose setup has been queued
     uint64_t group_submitted = 0; // groups whose tile kernels have been queued (<= group_seq)
@@ -1219,6 +1224,14 @@ int ensure_group_set(tr_scene *s, tr_scene::GroupSet &gs, uint32_t frames)
         const size_t tb = np * frames * (sizeof(SetupArgs) + sizeof(TileArgs));
         if ((st = dev_alloc(&gs.d_tables, tb))) return st;
         HIP_TRY(hipHostMalloc((void **)&gs.h_tables, tb, hipHostMallocDefault));
+        {
+            void *h = nullptr, *d = nullptr;
+            HIP_TRY(hipHostMalloc(&h, np * frames * LEN_WORDS * sizeof(uint32_t), hipHostMallocMapped));
+            memset(h, 0, np * frames * LEN_WORDS * sizeof(uint32_t));
+            HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+            gs.h_lens = (volatile uint32_t *)h;
+            gs.d_lens = (uint32_t *)d;
+        }
         gs.frames = frames;
     }
     if (gs.pool_cap != s->pool_cap) {
@@ -1245,6 +1258,9 @@ void free_group_set(tr_scene::GroupSet &gs)
     dev_free(gs.d_tables);
     if (gs.h_tables) (void)hipHostFree(gs.h_tables);
     gs.h_tables = nullptr;
+    if (gs.h_lens) (void)hipHostFree((void *)gs.h_lens);
+    gs.h_lens = nullptr;
+    gs.d_lens = nullptr;
     dev_free(gs.bins);
     gs.pool_cap = 0;
     gs.frames = 0;
@@ -1293,6 +1309,32 @@ int prepare_long_runs(tr_scene *s, bool own_colour)
 }
 
 int submit_groups(tr_scene *s, bool all);
+
+// (TR_WORK_UNITS=0: every tile kernel is launched with one workgroup per tile, as before round 4)
+static bool use_work_units()
+{
+    static const bool on = !getenv("TR_WORK_UNITS") || atoi(getenv("TR_WORK_UNITS")) != 0;
+    return on;
+}
+
+// Workgroups per frame for the tile kernels of pass `pi` of the group in `gs`, whose chain HAS COMPLETED (the caller has
+// seen its event), or 0: one per tile.  The tile kernel needs one workgroup per WORK UNIT -- a tile with polygons, or
+// EMPTY_CHUNK empty tiles (tr_kernels.hip) -- and k_bin_group, the chain's last kernel, has left every frame's list
+// lengths in page-locked memory: the frame that needs most decides (a fused launch's frames share the grid).
+static uint32_t group_units(const tr_scene *s, const tr_scene::GroupSet &gs, uint32_t pi, uint32_t n_tiles_pass)
+{
+    if (!gs.h_lens || s->mesh.n_tri == 0) return 0u;  // (no polygons: no k_bin)
+    uint32_t units = 0u;
+    for (uint32_t j = 0; j < gs.g; j++) {
+        const volatile uint32_t *w = gs.h_lens + ((size_t)pi * gs.frames + j) * LEN_WORDS;
+        uint32_t lens[8], sum = 0u;
+        for (int b = 0; b < 8; b++) sum += (lens[b] = w[b]);
+        if (sum != n_tiles_pass) return 0u;  // (not what a completed k_order leaves: take no chances)
+        const uint32_t u = tile_work_units(lens);
+        units = u > units ? u : units;
+    }
+    return units >= n_tiles_pass ? 0u : units;
+}
 
 // Queues the setup of g <= frames-per-group cleared frames, one launch per kernel and pass.  Frame j takes
 // light and camera from p[j], its targets from slot slot_of[j] and its colour buffer from fbs[j] (fbs == null:
@@ -1366,6 +1408,8 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
             sa.err = s->d_err;
             sa.alarm = s->d_alarm;
             sa.cells = gs.shared[pi] ? 1u : 0u;
+            sa.len_src = d_tile[e].list_len;
+            sa.len_host = gs.d_lens + e * LEN_WORDS;
             ta.bins = sa.bins;
             ta.pool_cap = s->pool_cap;
             ta.rec_pieces = s->rec_pieces;
@@ -1454,6 +1498,8 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
     const TileArgs *d_tile = reinterpret_cast<const TileArgs *>(gs.d_tables + (size_t)np * G * sizeof(SetupArgs));
     s->group_submitted++;
     if (wait_for_setup) HIP_TRY(hipStreamWaitEvent(s->stream, gs.ev_setup, 0));
+    // (has the chain completed?  "no wait needed" alone does not say so: a chain on the main stream itself needs none either)
+    const bool chain_done = !wait_for_setup && !gs.chain_on_main && hipEventQuery(gs.ev_setup) == hipSuccess;
     for (uint32_t pi = 0; pi < np; pi++) {
         const PassDesc &pass = pd.pass[pi];
         const TileArgs &ta0 = h_tile[(size_t)pi * G];
@@ -1466,8 +1512,11 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
         // (the group's "tiles done" event rides on its last tile kernel's own completion signal: a separate record
         // is one more packet between this group's tile kernel and the next one's)
         const bool last = pi + 1u == np;
+        // Workgroups per frame: exactly the pass's work units when its chain has completed (the host has seen the event:
+        // the lists' lengths are in page-locked memory), else one per tile
+        const uint32_t units = (chain_done && use_work_units()) ? group_units(s, gs, pi, ta0.frame.ntx * ta0.frame.nty) : 0u;
         int rc = launch_tile(tile_fs(s, pass.fs), ta0, tile_waves, shared, s->mesh.n_tri, d_tile + (size_t)pi * G, g, s->stream, ep.a,
-                             (!s->profiling && last) ? gs.ev_tile : ep.b);
+                             (!s->profiling && last) ? gs.ev_tile : ep.b, units);
         if (rc) {
             s->broken = true;  // (the group's chains have run: counters not zeroed, ranges never consumed)
             return launch_status(rc, "k_tile");
@@ -1490,8 +1539,8 @@ int submit_groups(tr_scene *s, bool all)
     int status = TR_OK;
     while (s->group_submitted < s->group_seq) {
         tr_scene::GroupSet &gs = s->grp[s->group_submitted % GROUP_SETS];
-        const bool ready = gs.chain_on_main || hipEventQuery(gs.ev_setup) == hipSuccess;  // (in order on the main stream: as good as done)
-        if (!ready && !all) {
+        bool ready = gs.chain_on_main || hipEventQuery(gs.ev_setup) == hipSuccess;  // (in order on the main stream: as good as done)
+        if (!ready) {
             // a main stream that has run dry (the first group of a call, typically) gets the group at once, behind
             // a wait: an idle GPU loses nothing to the packet, and a call of a few frames is mostly start-up
             // (20 frames at 4096^2: 40.3 -> 33 us per frame)
@@ -1499,7 +1548,15 @@ int submit_groups(tr_scene *s, bool all)
                               hipEventQuery(s->grp[(s->group_submitted - 1) % GROUP_SETS].ev_tile) == hipSuccess;
             // otherwise two groups are held back at most: the next setup needs the set of group_seq - GROUP_SETS,
             // whose tile kernels must be on the stream by then
-            if (!idle && s->group_seq - s->group_submitted <= 2) break;
+            if (!all && !idle && s->group_seq - s->group_submitted <= 2) break;
+            // It has to go now (the end of a call, or the host is about to sleep until a set is free).  While the main
+            // stream still has a tile kernel to run, the chain -- which runs beside that kernel and is far shorter --
+            // completes first: the HOST waits for it instead of a wait packet, and then knows the lists' lengths, i.e.
+            // how many workgroups the tile kernel really needs (group_units: a third of the tiles at 4096^2).
+            if (!idle && s->own_stream && use_work_units()) {
+                HIP_TRY(hipEventSynchronize(gs.ev_setup));
+                ready = true;
+            }
         }
         int st = submit_group_tiles(s, !ready);
         if (st != TR_OK && status == TR_OK) status = st;

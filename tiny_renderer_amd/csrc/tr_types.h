@@ -195,6 +195,11 @@ struct SetupArgs {
     uint32_t *lit;
     const uint32_t *texel_set;
     uint32_t tex_w, tex_h, set_bpr, lit_bpr;
+    // Fused launches: where k_bin -- the chain's last kernel -- leaves the pass's eight list lengths for the HOST
+    // (page-locked, mapped), which sizes LATER tile kernels' grids by them (k_tile, "work units"; tr_scene.cpp,
+    // group_units).  len_src: the lengths in the tile kernel's table entry (k_order's); len_host null: nothing is reported.
+    const uint32_t *len_src;
+    uint32_t *len_host;
 };
 
 struct TileArgs {
