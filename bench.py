@@ -714,6 +714,10 @@ def main():
                         "physical_frac": physical,
                         "limiter": "vector/scalar instruction issue of the tiles with polygons, not HBM "
                                    "(SQ counters under profiles/)",
+                        # `frac` is SURVEY 8d's ALGORITHMIC bytes over the launch's duration: an effective-bandwidth figure.
+                        # The kernel does not move those bytes -- the clear and the z of empty tiles are flags, a cleared
+                        # frame's depth stays in LDS -- so it can exceed 1; `physical_frac` is what crosses HBM.
+                        "frac_is": "algorithmic bytes / duration / peak (effective; the kernel moves `traffic` bytes: physical_frac)",
                         "avg_launch_us": round(avg_s * 1e6, 2), "frames_per_launch": round(frames_in_launch, 3),
                         "avg_launch_us_per_frame": round(avg_s * 1e6 / frames_in_launch, 2),
                         "algorithmic_bytes_per_launch": int(bytes_launch),
