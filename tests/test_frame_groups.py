@@ -554,3 +554,33 @@ def test_transient_depth_is_made_real_on_demand(small_synthetic, pipe):
         assert np.array_equal(gpu.read_z_f32().view(np.uint32), cpu.z_f32().view(np.uint32))
         cpu.close()
         gpu.close()
+
+
+@pytest.mark.parametrize("pipe", ["phong", "darboux"])   # (shadow's lookups leave the buffer under these cameras: upstream panics)
+def test_work_units_leave_no_tile_behind(small_synthetic, pipe):
+    """The tile kernel's grid is one workgroup per tile WITH polygons and one per 32 empty tiles, sized by the list
+    lengths of the frame of the group that needs most (k_bin_group reports them; the host launches behind a chain it has
+    seen complete) -- and one per tile when the lengths are not known (a call's first group).  Frames whose models sit
+    in different corners of the screen, so that every group holds frames with very different numbers of busy tiles and
+    most tiles flip between busy and empty from one frame of a slot to the next (an empty unit must clear what the
+    slot's previous frame left there): every frame the call leaves behind is the oracle's, in a call long enough for
+    exact grids (five groups) and again after per-frame renders."""
+    import tiny_renderer_amd as T
+    mesh, texs = small_synthetic
+    W = Hh = 1536   # 12 x 96 tiles: 36 chunks of empty tiles
+    n = 19
+    p = params(n, cam_step=0.31)
+    corners = [(0.0, 0.0), (0.9, 0.7), (-0.9, -0.7), (0.9, -0.7), (-1.6, 0.0), (0.0, 1.3)]
+    for i in range(n):
+        cx, cy = corners[i % len(corners)]
+        p[i, 6:9] = (cx, cy, 0.0)          # look_at: the model leaves the middle of the frame (partly the frame itself)
+    gpu = T.Scene(W, Hh, mesh, texs, pipe, frames_per_launch=4)
+    expect = oracle_frames(W, Hh, mesh, texs, pipe, p)
+    for rep in range(2):
+        gpu.render_frames(p)
+        assert gpu.sync() == 0
+        check_kept(gpu, expect, pipe, n)
+        q = p[3]
+        gpu.clear(), gpu.set_light_direction(q[0:3]), gpu.set_camera(q[3:6], q[6:9], q[9:12]), gpu.render()
+        assert np.array_equal(gpu.get_frame_buffer(), expect[3][0])
+    gpu.close()
