@@ -16,7 +16,6 @@
 #include <map>
 #include <mutex>
 #include <string>
-#include <chrono>
 #include <vector>
 
 #include "tiny_renderer.h"
@@ -328,9 +327,6 @@ struct tr_scene {
     // page-locked host word the kernels set beside d_err (TileArgs::alarm), and its device address
     volatile uint32_t *h_alarm = nullptr;
     uint32_t *d_alarm = nullptr;
-    // the completion event of the tile kernel queued last on the main stream (null: something else was, or nothing):
-    // what sync_and_status polls before it asks the runtime to wait for the stream
-    hipEvent_t last_tile_done = nullptr;
 
     // Lazy clear (scene.rs:128-137): `clear` only records that the targets are logically
     // f32::MIN / 0; the next render writes every pixel of them anyway, and a getter that comes
@@ -554,7 +550,6 @@ int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
     }
     s->tiles_submitted += 1;
     s->last_submitted_seq = t.p_seq;
-    s->last_tile_done = s->ev_tile[t.p_seq % RING];
     return status;
 }
 
@@ -791,13 +786,6 @@ int take_device_errors(tr_scene *s, uint32_t &err, unsigned long long &first_bad
     return TR_OK;
 }
 
-// (TR_SYNC_POLL=0: tr_scene_sync leaves the whole wait to hipStreamSynchronize, as before round 4)
-static bool sync_polls()
-{
-    static const bool on = !getenv("TR_SYNC_POLL") || atoi(getenv("TR_SYNC_POLL")) != 0;
-    return on;
-}
-
 // Waits for the stream and folds the device error word into a status.
 int sync_and_status(tr_scene *s)
 {
@@ -806,17 +794,6 @@ int sync_and_status(tr_scene *s)
         int sp = submit_pending(s);
         if (sp != TR_OK) return sp;
     }
-    // The last tile kernel's own completion signal is polled first (hipEventQuery reads the signal): the runtime's
-    // wait for a STREAM queues a marker behind the kernel and sleeps on that.  Whatever else is on the stream is
-    // waited for right after, as before.
-    if (s->last_tile_done && sync_polls()) {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (hipEventQuery(s->last_tile_done) == hipErrorNotReady) {
-            // (a long wait is not worth a spinning core: after 2 ms the runtime's blocking wait takes over)
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        }
-    }
-    s->last_tile_done = nullptr;
     HIP_TRY(hipStreamSynchronize(s->stream));
     uint32_t err = 0;
     unsigned long long first_bad = ~0ull;
@@ -1547,7 +1524,6 @@ int submit_group_tiles(tr_scene *s, bool wait_for_setup)
         if (s->profiling) s->events.push_back(ep);
     }
     if (s->profiling) HIP_TRY(hipEventRecord(gs.ev_tile, s->stream));
-    s->last_tile_done = gs.ev_tile;
     s->groups_unfenced = true;
     if (!s->own_stream) s->observed_seq = s->pass_seq;  // a caller's stream: handed on (see recover_from_overflow)
     return TR_OK;
