@@ -723,6 +723,10 @@ constexpr uint32_t SHARED_MAX_POLYGONS = 1u << 20, SHARED_MAX_SLOTS = 4093u;
 #ifndef TR_KEY_B64
 #define TR_KEY_B64 1
 #endif
+// (a depth pass stores the depth its resolve compared: k_tile, shade_steps)
+#ifndef TR_DEPTH_FROM_KEYS
+#define TR_DEPTH_FROM_KEYS 1
+#endif
 constexpr bool SCAN_ITEMS = TR_SCAN_ITEMS != 0;
 // Measurement builds only (wrong frames): leave a phase out to time the others (profiles/r03_notes.md)
 #ifndef TR_DBG_SKIP
@@ -1264,10 +1268,13 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const bool col_live = px < W;
 
     // Reads a pixel's key and returns the bin slot + 1 of its survivor (0: none)
-    auto survivor_slot = [&](uint32_t sx, uint32_t sy) -> uint32_t {
+    // (zbits: the f32 bits of the depth the resolve compared for that pixel -- what a depth pass stores, below)
+    auto survivor_slot = [&](uint32_t sx, uint32_t sy, uint32_t &zbits) -> uint32_t {
         if (SHARED && shared_tile) {
             // tie-break word: low 12 bits = bin slot + 1 of a fragment, 0xFFF / 0 = the buffer's old content
-            const uint32_t f = s_key[shared_key_slot((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)].x & 0xFFFu;
+            const uint2 key = s_key[shared_key_slot((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)];
+            const uint32_t f = key.x & 0xFFFu;
+            zbits = (key.y & 0x80000000u) ? key.y ^ 0x80000000u : ~key.y;  // (depth_order_bits undone; both zeros read +0)
             return (f == 0xFFFu) ? 0u : f;
         }
         // (the whole 8-byte key: 64 lanes x 8 bytes in a row are conflict-free as ds_read_b64, the upper dwords alone as
@@ -1276,8 +1283,10 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         const uint2 key = s_key[key_slot<QUAD_COLUMN>((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)];
         uint32_t keep = key.x;
         asm volatile("" : "+v"(keep));   // (keeps the compiler from narrowing the read again)
+        zbits = keep;
         return key.y;
 #else
+        zbits = 0u;
         return s_key[key_slot<QUAD_COLUMN>((uint32_t)strip_x + sx, (uint32_t)strip_y + sy)].y;
 #endif
     };
@@ -1480,19 +1489,33 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
         if (!((step_mask >> sstep) & 1u)) continue;
         int32_t row[2], py[2];
         bool live[2], won[2];
-        uint32_t wslot[2];
+        uint32_t wslot[2], zkey[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             row[u] = sstep * 4 + u * 2 + hrow;  // within the strip
             py[u] = sy0 + row[u];
             live[u] = col_live && py[u] >= band_y0 && py[u] < band_y1;
-            const uint32_t s1 = survivor_slot((uint32_t)hx, (uint32_t)row[u]);
+            const uint32_t s1 = survivor_slot((uint32_t)hx, (uint32_t)row[u], zkey[u]);
             won[u] = live[u] && s1 != 0u;
             wslot[u] = won[u] ? s1 - 1u : 0u;
         }
         uint32_t tri[2] = { NO_WINNER, NO_WINNER }, rgb[2] = { 0u, 0u };
         float zout[2] = { bits_f32(TR_F32_MIN_BITS), bits_f32(TR_F32_MIN_BITS) };
-        if (!(TR_DBG_SKIP & 1) && __any(won[0] || won[1])) {
+        // A depth pass (shader.rs:694-709, 832-847) stores the survivor's z and nothing else -- and the resolve has
+        // computed exactly that value: the same polygon, the same pixel, the same operations (barycentric2_for_compare
+        // differs from barycentric2 only in the SIGN of a zero quotient, which reaches the sum only when the sum is itself
+        // a zero).  So the key's depth IS the stored depth unless it is a zero; a step with a zero among its survivors'
+        // depths takes the fragment stage as before.  No record gather, no cross products, no quotients for the rest:
+        // the depth pass of the reference's model at 4096^2 22.5 -> see profiles/r04_notes.md.
+        bool from_keys = false;
+        if (DEPTH && TR_DEPTH_FROM_KEYS && TR_KEY_B64) {
+            from_keys = !__any((won[0] && (zkey[0] << 1) == 0u) || (won[1] && (zkey[1] << 1) == 0u));
+            if (from_keys) {
+                if (won[0]) zout[0] = __uint_as_float(zkey[0]);
+                if (won[1]) zout[1] = __uint_as_float(zkey[1]);
+            }
+        }
+        if (!(TR_DBG_SKIP & 1) && !from_keys && __any(won[0] || won[1])) {
             const int32_t pxs[2] = { px, px };
             if (shade_two(in_lds, pair_tag, pxs, py, won, wslot, zout, rgb, tri)) redo |= 1u << sstep;
         }
