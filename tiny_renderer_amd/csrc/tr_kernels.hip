@@ -524,12 +524,24 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order(TileArgs one, uint32_t 
 
 // LDS index of pixel (qx, qy) of a quadrant: block-major, so that during coverage lane l of a
 // wave touches slot (block*64 + l): conflict-free 8-byte accesses.
+// Inside a block the rows are exchanged by the block's column within its 32-pixel strip (row ^ column & 3): the shading
+// phase reads a ROW of 32 keys per half-wave -- four blocks' eight-key pieces, which without the exchange start in the
+// same bank (blocks are 512 bytes apart): a four-way conflict on every survivor read, 1.7 M of the headline launch's
+// 2.8 M conflict cycles.  During coverage a wave's 64 lanes still cover exactly one block: any order of its rows is
+// conflict-free there.
+#ifndef TR_KEY_SWIZZLE
+#define TR_KEY_SWIZZLE 1
+#endif
+__device__ __forceinline__ uint32_t key_row_swizzle(uint32_t tx)  // tx: x within the tile
+{
+    return TR_KEY_SWIZZLE ? ((tx >> 3) & 3u) << 3 : 0u;
+}
 template <int QUAD>
 __device__ __forceinline__ uint32_t key_slot(uint32_t tx, uint32_t qy)
 {
     constexpr int NBX = QUAD / 8, QPIX = QUAD * TILE_H;
     const uint32_t qx = tx % (uint32_t)QUAD;
-    return (tx / (uint32_t)QUAD) * (uint32_t)QPIX + (((qy >> 3) * NBX + (qx >> 3)) << 6) + ((qy & 7u) << 3) + (qx & 7u);
+    return (tx / (uint32_t)QUAD) * (uint32_t)QPIX + (((qy >> 3) * NBX + (qx >> 3)) << 6) + ((((qy & 7u) << 3) + (qx & 7u)) ^ key_row_swizzle(tx));
 }
 
 // Key layout of the SHARED resolve: row-major, the 8-pixel groups of a row rotated by the row number.
@@ -950,7 +962,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                     if (px < W && py >= band_y0 && py < band_y1)
                         zb = __float_as_uint(gload(depth + ((size_t)py * W + px)));
                 }
-                wkey[(b << 6) + lane] = make_uint2(zb, 0u);
+                wkey[(b << 6) + (lane ^ key_row_swizzle((uint32_t)((int32_t)wave * QUAD + (b % NBX) * 8)))] = make_uint2(zb, 0u);
             }
         }
 
@@ -1047,7 +1059,8 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
                         cols &= cols - 1u;
                         // the two pixels' current keys, requested before the arithmetic that decides
                         // whether they are needed (LDS latency hidden inside the wave)
-                        uint2 *slot_a = SH ? wkey + (key_lane ^ ((uint32_t)ib << 3)) : wkey + ((ib << 6) + (int32_t)lane);
+                        uint2 *slot_a = SH ? wkey + (key_lane ^ ((uint32_t)ib << 3))
+                                           : wkey + (((uint32_t)ib << 6) + (lane ^ key_row_swizzle((uint32_t)((int32_t)wave * QUAD + ib * 8))));
                         uint2 *slot_b = slot_a + (SH ? 8 * TILE_W : NBX << 6);
                         const uint2 cur_a = *slot_a, cur_b = *slot_b;
                         const int32_t px = qx0 + ib * 8 + lx;
