@@ -40,7 +40,8 @@ int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bo
 // largest frame; 0 = one per tile, which always suffices).
 uint32_t tile_work_units(const uint32_t lengths[8]);
 int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
-                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done, uint32_t units_per_frame = 0);
+                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done, uint32_t units_per_frame = 0,
+                bool fused_single = false);
 int launch_materialize_depth(float *zbuf, uint32_t *zclean, const DevFrame &frame, hipStream_t st);
 // The band's tiles of frame buffer `fb` into the page-locked host buffer `host` (device address of it), skipping the
 // tiles that are zeros on both sides (fb_clean: the target's colour-clean flags; host_clean: the host buffer's own)

@@ -810,7 +810,15 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     const uint32_t n_fr = GROUP ? n_frames : 1u;
     const uint32_t frame_of_group = blockIdx.x % n_fr;
     // (the table entry is not copied: a member is loaded where it is used, arrays are indexed in place)
-    const TileArgs &a = GROUP ? *(const TileArgs *)((constant_ptr<TileArgs>)table + frame_of_group) : args;
+    // (a fused-mode launch of ONE frame -- a per-frame pass that starts from cleared targets, launch_tile's `fused_single` --
+    // has no table in memory: its arguments are `args`, the kernel's first parameter, read in place in the kernel-argument
+    // segment like a table entry)
+    const TileArgs &a = GROUP ? *(const TileArgs *)(table ? (constant_ptr<TileArgs>)table + frame_of_group
+                                                         : (constant_ptr<TileArgs>)__builtin_amdgcn_kernarg_segment_ptr())
+                              : args;
+    // a fused launch has the eight lengths in its table entry, a per-frame launch (fused-mode or not) behind the pass's
+    // counters (one more scalar load)
+    const bool table_lengths = GROUP && table != nullptr;
     // (every frame of a fused launch starts from cleared targets and has no winner tap -- run_group, tr_scene.cpp: known
     // when the kernel is compiled, so the accumulate paths and the tap's stores are not even there)
     const bool fresh = GROUP || a.fresh != 0u;
@@ -828,7 +836,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     {
         // which list, which entry: a fused launch has the eight lengths in its table entry, a per-frame launch
         // behind the pass's counters (one more scalar load)
-        constant_ptr<uint32_t> lengths = GROUP ? (constant_ptr<uint32_t>)a.list_len : (constant_ptr<uint32_t>)a.tile_count + n_tiles;
+        constant_ptr<uint32_t> lengths = table_lengths ? (constant_ptr<uint32_t>)a.list_len : (constant_ptr<uint32_t>)a.tile_count + n_tiles;
 #pragma unroll
         for (int b = 0; b < ORDER_BUCKETS - 1; b++) {
             const uint32_t len = lengths[b];
@@ -841,7 +849,7 @@ TR_TILE_KERNEL_ATTRS void k_tile(TileArgs args, const TileArgs *__restrict__ tab
     uint64_t *const stamps = frame_of_group == 0u ? a.stamps : nullptr;  // the diagnostic stamps follow a group's first frame
     if (list == (uint32_t)ORDER_EMPTY) {
         // ---- a chunk of the empty list: EMPTY_CHUNK tiles without polygons (work unit `entry` behind the busy tiles) ----
-        constant_ptr<uint32_t> lens = GROUP ? (constant_ptr<uint32_t>)a.list_len : (constant_ptr<uint32_t>)a.tile_count + n_tiles;
+        constant_ptr<uint32_t> lens = table_lengths ? (constant_ptr<uint32_t>)a.list_len : (constant_ptr<uint32_t>)a.tile_count + n_tiles;
         const uint32_t n_empty = lens[ORDER_EMPTY], first = entry * EMPTY_CHUNK;
         if (first >= n_empty || !fresh) return;  // (surplus workgroup of a grid sized for the worst case; an accumulating render leaves empty tiles alone)
         const uint32_t cnt = min(EMPTY_CHUNK, n_empty - first);
@@ -1961,18 +1969,23 @@ int launch_order(const TileArgs &one, uint32_t n_tiles, const TileArgs *group, u
 
 template <int WAVES, bool SHARED>
 static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const TileArgs *group, uint32_t n_frames,
-                             hipStream_t st, hipEvent_t start, hipEvent_t done)
+                             hipStream_t st, hipEvent_t start, hipEvent_t done, bool fused_single)
 {
+    // fused_single: ONE frame that starts from cleared targets and has no winner tap runs the fused launches' kernels
+    // (compiled for exactly that: no accumulate paths, no tap, eight workgroups per CU, depth left on the chip when
+    // a.store says so) with its arguments by value: no table (`group` null), one frame.
+    const bool fused = group != nullptr || fused_single;
+    if (fused_single && !group) n_frames = 1u;
     // (n_tiles here: the workgroups per frame -- the frame's tiles, or the work units a host that knows the lists'
     // lengths asks for, tile_work_units)
-    const dim3 grid(n_tiles * (group ? n_frames : 1u)), block(64 * WAVES);
+    const dim3 grid(n_tiles * (fused ? n_frames : 1u)), block(64 * WAVES);
     // (a fused launch whose frames leave their depth on the chip: `a` -- what the group's frames have in common -- says so)
-    const bool transient = group && fs != FS_DEPTH && a.store == TR_STORE_COLOR;
+    const bool transient = fused && fs != FS_DEPTH && a.store == TR_STORE_COLOR;
 #define TR_TILE_CASE(F)                                                                                                  \
     case F:                                                                                                              \
         if (transient)                                                                                                   \
             hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, (F == FS_DEPTH ? 1 : 2)>), grid, block, 0, st, start, done, 0, a, group, n_frames); \
-        else if (group)                                                                                                  \
+        else if (fused)                                                                                                  \
             hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, 1>), grid, block, 0, st, start, done, 0, a, group, n_frames); \
         else                                                                                                             \
             hipExtLaunchKernelGGL((k_tile<F, WAVES, SHARED, 0>), grid, block, 0, st, start, done, 0, a, nullptr, 0u); \
@@ -2002,7 +2015,7 @@ uint32_t tile_work_units(const uint32_t lengths[8])
 }
 
 int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
-                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done, uint32_t units_per_frame)
+                uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done, uint32_t units_per_frame, bool fused_single)
 {
     uint32_t n_tiles = a.frame.ntx * a.frame.nty;
     if (n_tiles == 0) return 0;
@@ -2010,16 +2023,17 @@ int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t 
     if (units_per_frame != 0u && units_per_frame < n_tiles) n_tiles = units_per_frame;
     if ((int)a.rec_pieces != rec_pieces_for_fs(fs)) return (int)hipErrorInvalidValue;
     if (group && (n_frames == 0 || (uint64_t)n_tiles * n_frames > 0x7FFFFFFFull)) return (int)hipErrorInvalidValue;
+    if (fused_single && (group || a.fresh == 0u || a.winner)) return (int)hipErrorInvalidValue;  // (what those kernels are compiled for)
     // the shared keys pack polygon id and bin slot into 32 bits: beyond their fields, resolve by columns
     if (n_polygons > SHARED_MAX_POLYGONS) shared = 0;  // (a tile with more records than the slot field holds resolves by columns: k_tile)
     if (shared) {
-        if (tile_waves == 16) return launch_tile_waves<16, true>(fs, a, n_tiles, group, n_frames, st, start, done);
-        if (tile_waves == 8) return launch_tile_waves<8, true>(fs, a, n_tiles, group, n_frames, st, start, done);
-        if (tile_waves == 4) return launch_tile_waves<4, true>(fs, a, n_tiles, group, n_frames, st, start, done);
+        if (tile_waves == 16) return launch_tile_waves<16, true>(fs, a, n_tiles, group, n_frames, st, start, done, fused_single);
+        if (tile_waves == 8) return launch_tile_waves<8, true>(fs, a, n_tiles, group, n_frames, st, start, done, fused_single);
+        if (tile_waves == 4) return launch_tile_waves<4, true>(fs, a, n_tiles, group, n_frames, st, start, done, fused_single);
     } else {
-        if (tile_waves == 16) return launch_tile_waves<16, false>(fs, a, n_tiles, group, n_frames, st, start, done);
-        if (tile_waves == 8) return launch_tile_waves<8, false>(fs, a, n_tiles, group, n_frames, st, start, done);
-        if (tile_waves == 4) return launch_tile_waves<4, false>(fs, a, n_tiles, group, n_frames, st, start, done);
+        if (tile_waves == 16) return launch_tile_waves<16, false>(fs, a, n_tiles, group, n_frames, st, start, done, fused_single);
+        if (tile_waves == 8) return launch_tile_waves<8, false>(fs, a, n_tiles, group, n_frames, st, start, done, fused_single);
+        if (tile_waves == 4) return launch_tile_waves<4, false>(fs, a, n_tiles, group, n_frames, st, start, done, fused_single);
     }
     return (int)hipErrorInvalidValue;
 }

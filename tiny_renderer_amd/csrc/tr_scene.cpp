@@ -206,6 +206,7 @@ struct tr_scene {
     uint64_t pass_seq = 0;
     struct PendingTile {
         int fs, tile_waves, shared, kernel_id;
+        bool fused_single = false;  // the pass starts from cleared targets without a winner tap: the fused launches' kernels (launch_tile)
         uint64_t p_seq;
         TileArgs args;
     };
@@ -536,12 +537,13 @@ int launch_pending_tile(tr_scene *s, const tr_scene::PendingTile &t)
 {
     int status = TR_OK;
     if (!s->profiling) {
-        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, nullptr, s->ev_tile[t.p_seq % RING]);
+        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, nullptr, s->ev_tile[t.p_seq % RING], 0u,
+                             t.fused_single);
         if (rc) status = launch_status(rc, "k_tile");
         if (rc) s->broken = true;  // (its chain has run: the set's counters were not zeroed, the pass's ranges never consumed)
     } else {
         EventPair ep = { take_event(s), take_event(s), t.kernel_id, 1u };
-        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, ep.a, ep.b);
+        int rc = launch_tile(t.fs, t.args, t.tile_waves, t.shared, s->mesh.n_tri, nullptr, 0, s->stream, ep.a, ep.b, 0u, t.fused_single);
         if (rc) status = launch_status(rc, "k_tile");
         if (rc) s->broken = true;
         s->events.push_back(ep);
@@ -906,6 +908,13 @@ bool defer_depth(const tr_scene *s)
     return env_on && s->transient_depth && !s->d_winner && !s->d_stamps;
 }
 
+// (TR_FUSED_SINGLE=0: a per-frame pass runs the per-frame kernels whatever its targets' state, as before round 4)
+static bool fused_single_launches()
+{
+    static const bool on = !getenv("TR_FUSED_SINGLE") || atoi(getenv("TR_FUSED_SINGLE")) != 0;
+    return on;
+}
+
 // depth_only: the repeat of a colour pass for its depth alone (ensure_depth): from cleared targets, nothing of the
 // scene's clear / colour state is consumed or changed.
 int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
@@ -989,13 +998,19 @@ int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
             ta.winner = nullptr;
             ta.stamps = nullptr;
             slot.z_deferred = false;
+        } else if (fresh && !s->d_winner && defer_depth(s) && fused_single_launches()) {
+            // a cleared frame on its own: the fused launches' kernel for one frame (launch_tile, fused_single), and like
+            // a group's frames it leaves its depth on the chip; whoever wants the z buffer gets it from ensure_depth
+            ta.store = TR_STORE_COLOR;
+            slot.z_deferred = true;
+            memcpy(slot.z_params.light, s->light, 12); memcpy(slot.z_params.look_from, s->from, 12);
+            memcpy(slot.z_params.look_at, s->at, 12); memcpy(slot.z_params.up, s->up, 12);
         } else {
-            // (a per-frame launch writes its depth: only the fused launches of frame groups leave it on the chip --
-            // decided at compile time there, k_tile's MODE -- and an accumulating render has had the slot's depth made
-            // real before it came here: ensure_depth, tr_scene_render)
+            // (an accumulating render has had the slot's depth made real before it came here: ensure_depth, tr_scene_render)
             slot.z_deferred = false;
         }
     }
+    pt.fused_single = !depth_only && fresh != 0u && !s->d_winner && fused_single_launches();
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     if (!depth_only) ta.stamps = depth_pass ? nullptr : s->d_stamps;
