@@ -466,6 +466,21 @@ int use_slot(tr_scene *s, int k, uint8_t *fb, bool handed_over = false)
     return select_fb_flags(s, handed_over);
 }
 
+// The z buffer of frame slot k, allocated the first time a pass will read or write it.  The slots of frame groups
+// (ensure_slots) start without one: a cleared frame's colour pass leaves its depth on the chip (transient depth), so a
+// slot's z memory is touched only by a depth-only repeat (ensure_depth), an accumulating render or a scene that stores
+// its depth -- 64 MiB per slot at 4096^2 that a running loop never uses (32 slots: 2 of the scene's 5 GB).
+int need_z(tr_scene *s, int k)
+{
+    tr_scene::FrameSlot &fs = s->slots[(size_t)k];
+    if (!fs.z) {
+        int st = dev_alloc(&fs.z, (size_t)s->width * s->height);
+        if (st != TR_OK) return st;
+    }
+    if (k == s->cur_slot) s->d_z = fs.z;
+    return TR_OK;
+}
+
 hipEvent_t take_event(tr_scene *s)
 {
     if (!s->event_pool.empty()) {
@@ -665,6 +680,10 @@ int materialize_depth(tr_scene *s)
     {
         int sp = submit_pending(s);
         if (sp != TR_OK) return sp;
+    }
+    {
+        int st = need_z(s, s->cur_slot);
+        if (st != TR_OK) return st;
     }
     int rc = launch_materialize_depth(s->d_z, s->d_zclean, s->frame, s->stream);
     if (rc) return launch_status(rc, "k_materialize_depth");
@@ -1011,6 +1030,11 @@ int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
         }
     }
     pt.fused_single = !depth_only && fresh != 0u && !s->d_winner && fused_single_launches();
+    if (!depth_pass && ((ta.store & TR_STORE_DEPTH) || fresh == 0u)) {   // the pass reads or writes z memory
+        st = need_z(s, s->cur_slot);
+        if (st != TR_OK) return st;
+        ta.zbuf = s->d_z;
+    }
     ta.aligned16 = (s->width % 16u == 0u) ? 1u : 0u;
     ta.aligned4 = (s->width % 4u == 0u) ? 1u : 0u;
     if (!depth_only) ta.stamps = depth_pass ? nullptr : s->d_stamps;
@@ -1184,8 +1208,8 @@ int ensure_slots(tr_scene *s, uint32_t n)
     const size_t npx = (size_t)s->width * s->height;
     while (s->slots.size() < n) {
         tr_scene::FrameSlot fs;
-        int st = dev_alloc(&fs.z, npx);
-        if (st == TR_OK) st = dev_alloc(&fs.zclean, (size_t)s->n_tiles);
+        // (no z buffer yet: need_z)
+        int st = dev_alloc(&fs.zclean, (size_t)s->n_tiles);
         if (st == TR_OK && kPipelines[s->pipeline].n_passes == 2) st = dev_alloc(&fs.shadow, npx);
         if (st == TR_OK && kPipelines[s->pipeline].n_passes == 2) st = dev_alloc(&fs.sclean, (size_t)s->n_tiles_full);
         if (st != TR_OK) {
@@ -1394,6 +1418,8 @@ int run_group(tr_scene *s, const tr_frame_params *p, void *const *fbs, const int
     for (uint32_t j = 0; j < g && st == TR_OK; j++) {
         memcpy(s->light, p[j].light, 12); memcpy(s->from, p[j].look_from, 12);
         memcpy(s->at, p[j].look_at, 12); memcpy(s->up, p[j].up, 12);
+        if (!defer_depth(s)) st = need_z(s, slot_of[j]);   // (the frames store their depth)
+        if (st != TR_OK) break;
         tr_scene::FrameSlot &slot = s->slots[(size_t)slot_of[j]];
         slot.z_deferred = defer_depth(s);   // (what the slot's z is then: this frame)
         slot.z_params = p[j];
