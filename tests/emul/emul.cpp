@@ -520,6 +520,12 @@ int tr_emul_plan_handover(uint32_t pending, int nothing_submitted, int newest_ti
     return (int)tr::plan::handover(pending, nothing_submitted != 0, newest_tile_done != 0);
 }
 
+uint32_t tr_emul_plan_grid_units(const uint32_t *lengths, uint32_t frames, uint32_t n_tiles)
+{
+    return tr::plan::group_grid_units(lengths, frames, n_tiles);
+}
+uint32_t tr_emul_plan_work_units(const uint32_t *lengths) { return tr::plan::work_units(lengths); }
+
 void tr_emul_plan_constants(int *out)
 {
     out[0] = tr::plan::GROUP_MAX; out[1] = tr::plan::GROUP_SETS; out[2] = tr::plan::LOOKAHEAD; out[3] = tr::plan::BATCH;

@@ -18,6 +18,10 @@ from tests import emul_bind as E
 def L():
     lib = E.lib()
     lib.tr_emul_plan_call.restype = C.c_uint32
+    lib.tr_emul_plan_grid_units.restype = C.c_uint32
+    lib.tr_emul_plan_grid_units.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.tr_emul_plan_work_units.restype = C.c_uint32
+    lib.tr_emul_plan_work_units.argtypes = [C.c_void_p]
     lib.tr_emul_plan_grown_pool.restype = C.c_uint64
     lib.tr_emul_plan_grown_pool.argtypes = [C.c_uint64, C.c_uint64]
     lib.tr_emul_plan_overflow.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
@@ -250,3 +254,31 @@ def test_the_host_stays_within_nine_passes_of_the_gpu(progress, two_setup_stream
         submit_front(True)
     advance(100000)
     assert len(tile_done) == issued and len(setup_done) == issued
+
+
+@given(st.lists(st.lists(st.integers(0, 5000), min_size=8, max_size=8), min_size=1, max_size=32), st.integers(0, 3))
+@settings(max_examples=300, deadline=None)
+def test_the_tile_kernels_grid_covers_every_work_unit(lens, spoil):
+    """tr_plan.h work_units / group_grid_units: a tile kernel takes one workgroup per tile WITH polygons and one per 32 entries
+    of the empty list; a fused launch's frames share the grid.  Whatever the lists' lengths: the grid the host asks for
+    holds every unit of every frame, never more workgroups than one per tile, exactly the largest frame's units -- and 0
+    (= one per tile) as soon as a frame's lengths do not add up to the pass's tiles (words a chain has not written yet)."""
+    lib = L()
+    n_tiles = sum(lens[0])
+    frames = [list(f) for f in lens]
+    for f in frames:      # every frame of a pass has the same number of tiles: move the difference into the empty list
+        d = n_tiles - sum(f[:7])
+        if d < 0:
+            f[:7] = [0] * 7
+            d = n_tiles
+        f[7] = d
+    flat = (C.c_uint32 * (8 * len(frames)))(*[v for f in frames for v in f])
+    units = [lib.tr_emul_plan_work_units((C.c_uint32 * 8)(*f)) for f in frames]
+    for f, u in zip(frames, units):
+        busy, empty = sum(f[:7]), f[7]
+        assert u == busy + (empty + 31) // 32 and u <= max(n_tiles, 1)
+    got = lib.tr_emul_plan_grid_units(flat, len(frames), n_tiles)
+    assert got == (max(units) if max(units) < n_tiles else 0)
+    if spoil and n_tiles:
+        flat[8 * (spoil % len(frames)) + 7] += 1     # a frame whose words are not a completed k_order's
+        assert lib.tr_emul_plan_grid_units(flat, len(frames), n_tiles) == 0

@@ -36,9 +36,8 @@ int launch_bin(const SetupArgs &a, const SetupArgs *group, uint32_t n_frames, bo
 // tile_waves: 4, 8 or 16 wavefronts per tile workgroup (see tr_types.h); shared != 0: the waves share the
 // tile's bin and resolve through atomic keys instead of each owning a column of the tile (k_tile's
 // SHARED parameter; falls back to columns when n_polygons or a.bin_cap exceed the key's fields).
-// units_per_frame: workgroups per frame when the caller knows the pass's list lengths (tile_work_units of the
-// largest frame; 0 = one per tile, which always suffices).
-uint32_t tile_work_units(const uint32_t lengths[8]);
+// units_per_frame: workgroups per frame when the caller knows the pass's list lengths (tr_plan.h, group_grid_units;
+// 0 = one per tile, which always suffices).
 int launch_tile(int fs_kind, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,
                 uint32_t n_frames, hipStream_t st, hipEvent_t start, hipEvent_t done, uint32_t units_per_frame = 0,
                 bool fused_single = false);

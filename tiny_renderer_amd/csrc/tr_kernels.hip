@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "tr_kernels.h"
+#include "tr_plan.h"
 #include "tr_shaders.h"
 
 namespace tr {
@@ -396,7 +397,8 @@ static_assert(ORDER_BUCKETS == 8, "k_bin_group reports eight list lengths");
 // (measured with a grid cut behind the busy tiles, profiles/r04_notes.md).  A launch needs
 // units(lengths) = busy + ceil(empty / EMPTY_CHUNK) workgroups per frame; any larger grid is correct (the surplus
 // exits at once), n_tiles always suffices, and a host that knows the lengths (SetupArgs::len_host) asks for no more.
-constexpr uint32_t EMPTY_CHUNK = 32u;
+using plan::EMPTY_CHUNK;
+static_assert(plan::ORDER_LISTS_ == (uint32_t)ORDER_BUCKETS, "tr_plan.h counts the lists the tile kernel walks");
 
 // Bijection on [0, n): odd multiplications and xor-shifts are bijections on [0, 2^bits); values
 // that fall outside [0, n) are walked through the same map again (cycle walking).
@@ -1977,7 +1979,7 @@ static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const 
     const bool fused = group != nullptr || fused_single;
     if (fused_single && !group) n_frames = 1u;
     // (n_tiles here: the workgroups per frame -- the frame's tiles, or the work units a host that knows the lists'
-    // lengths asks for, tile_work_units)
+    // lengths asks for, plan::work_units)
     const dim3 grid(n_tiles * (fused ? n_frames : 1u)), block(64 * WAVES);
     // (a fused launch whose frames leave their depth on the chip: `a` -- what the group's frames have in common -- says so)
     const bool transient = fused && fs != FS_DEPTH && a.store == TR_STORE_COLOR;
@@ -2005,13 +2007,6 @@ static int launch_tile_waves(int fs, const TileArgs &a, uint32_t n_tiles, const 
 #undef TR_TILE_CASE
     TR_LAUNCH_CHECK();
     return 0;
-}
-
-uint32_t tile_work_units(const uint32_t lengths[8])
-{
-    uint32_t busy = 0u;
-    for (int b = 0; b < ORDER_EMPTY; b++) busy += lengths[b];
-    return busy + (lengths[ORDER_EMPTY] + EMPTY_CHUNK - 1u) / EMPTY_CHUNK;
 }
 
 int launch_tile(int fs, const TileArgs &a, int tile_waves, int shared, uint32_t n_polygons, const TileArgs *group,

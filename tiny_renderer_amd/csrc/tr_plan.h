@@ -19,6 +19,37 @@ constexpr int GROUP_SETS = 4;   // groups in flight: group g's setup reuses the 
 constexpr int LOOKAHEAD = 5;    // per-frame path: setup of pass p is ordered (on the device) after the tile kernel of pass p - LOOKAHEAD
 constexpr int BATCH = LOOKAHEAD - 1;  // passes whose setup is queued and whose tile kernel the host still holds
 
+// ---- the tile kernel's grid ---------------------------------------------------------------------------------------
+// A pass's tiles are sorted into eight lists (k_order): seven by weight, the last the tiles without polygons.  The tile
+// kernel takes one workgroup per WORK UNIT: a tile with polygons, or EMPTY_CHUNK entries of the empty list (a workgroup
+// per empty tile was four waves and 20 KiB of LDS dispatched to read one flag).  A launch needs work_units(lengths)
+// workgroups per frame; any larger grid is correct (the surplus exits at once) and one per tile always suffices, so a
+// host that does not know the lengths asks for that -- and one that does (the chain has completed: k_bin_group reports
+// them) asks for exactly the units of the frame that needs most.
+constexpr uint32_t ORDER_LISTS_ = 8u;     // (= ORDER_BUCKETS, tr_kernels.hip)
+constexpr uint32_t EMPTY_CHUNK = 32u;     // empty tiles per workgroup
+inline uint32_t work_units(const uint32_t lengths[ORDER_LISTS_])
+{
+    uint32_t busy = 0u;
+    for (uint32_t b = 0; b + 1u < ORDER_LISTS_; b++) busy += lengths[b];
+    return busy + (lengths[ORDER_LISTS_ - 1u] + EMPTY_CHUNK - 1u) / EMPTY_CHUNK;
+}
+// The grid of a fused launch of `frames` frames whose list lengths are `lengths[f][8]`: the largest frame's units, or 0
+// (= one workgroup per tile) when a frame's lengths do not add up to the pass's tiles -- not what a completed k_order
+// leaves -- or when nothing would be saved.
+inline uint32_t group_grid_units(const uint32_t *lengths, uint32_t frames, uint32_t n_tiles)
+{
+    uint32_t units = 0u;
+    for (uint32_t f = 0; f < frames; f++) {
+        uint32_t sum = 0u;
+        for (uint32_t b = 0; b < ORDER_LISTS_; b++) sum += lengths[f * ORDER_LISTS_ + b];
+        if (sum != n_tiles) return 0u;
+        const uint32_t u = work_units(lengths + f * ORDER_LISTS_);
+        units = u > units ? u : units;
+    }
+    return units >= n_tiles ? 0u : units;
+}
+
 // ---- frames per fused launch ---------------------------------------------------------------------------------------
 struct SceneShape {
     uint32_t n_tiles;             // 128 x 16 tiles of the scene's band

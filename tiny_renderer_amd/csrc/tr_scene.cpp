@@ -1362,17 +1362,11 @@ static bool use_work_units()
 // lengths in page-locked memory: the frame that needs most decides (a fused launch's frames share the grid).
 static uint32_t group_units(const tr_scene *s, const tr_scene::GroupSet &gs, uint32_t pi, uint32_t n_tiles_pass)
 {
-    if (!gs.h_lens || s->mesh.n_tri == 0) return 0u;  // (no polygons: no k_bin)
-    uint32_t units = 0u;
-    for (uint32_t j = 0; j < gs.g; j++) {
-        const volatile uint32_t *w = gs.h_lens + ((size_t)pi * gs.frames + j) * LEN_WORDS;
-        uint32_t lens[8], sum = 0u;
-        for (int b = 0; b < 8; b++) sum += (lens[b] = w[b]);
-        if (sum != n_tiles_pass) return 0u;  // (not what a completed k_order leaves: take no chances)
-        const uint32_t u = tile_work_units(lens);
-        units = u > units ? u : units;
-    }
-    return units >= n_tiles_pass ? 0u : units;
+    if (!gs.h_lens || s->mesh.n_tri == 0 || gs.g > (uint32_t)GROUP_MAX) return 0u;  // (no polygons: no k_bin)
+    uint32_t lens[GROUP_MAX * LEN_WORDS];
+    const volatile uint32_t *w = gs.h_lens + (size_t)pi * gs.frames * LEN_WORDS;
+    for (uint32_t i = 0; i < gs.g * LEN_WORDS; i++) lens[i] = w[i];
+    return plan::group_grid_units(lens, gs.g, n_tiles_pass);
 }
 
 // Queues the setup of g <= frames-per-group cleared frames, one launch per kernel and pass.  Frame j takes
