@@ -971,7 +971,7 @@ int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
     tr_scene::PendingTile pt;
     tile_layout(s, n_tiles_pass, n_tiles_pass, pt.tile_waves, pt.shared);
 
-    SetupArgs sa;
+    SetupArgs sa = {};   // (every member defined: the kernels take the struct by value)
     sa.mesh = s->mesh;
     sa.frame = frame;
     sa.u = du;
@@ -987,7 +987,7 @@ int run_pass(tr_scene *s, const PassDesc &p, bool depth_only = false)
     sa.rec_pieces = s->rec_pieces;
     sa.err = s->d_err;
     sa.alarm = s->d_alarm;
-    TileArgs ta;
+    TileArgs ta = {};
     ta.bins = bins;
     ta.pool_cap = s->pool_cap;
     ta.rec_pieces = s->rec_pieces;
